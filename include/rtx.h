@@ -1,0 +1,175 @@
+/*
+ * rtx.h -- C ABI of librtx, the MI355X (gfx950) implementation of the reference
+ * path tracer's per-pixel trace loop.
+ *
+ * The reference has no plugin or FFI interface.  The seam this library replaces
+ * is the Rust function `fn render(scene: &mut Scene)` (src/main.rs:13-31), which
+ * `main` calls once between `parse_scene` and `color_correction`
+ * (src/main.rs:37-41): input = the parsed Scene (src/parser.rs:12-24), output =
+ * linear mean radiance per pixel in Image.data (src/image.rs:6-29).
+ *
+ * All structs are plain data, little-endian, IEEE binary32.  The caller owns
+ * every pointer it passes; the library copies what it needs during the call and
+ * keeps no caller pointer.  No function aborts or throws: each returns
+ * RTX_OK (0) or a negative rtx_status, and rtx_last_error() gives a message for
+ * the calling thread's last failure.  One rtx_ctx belongs to one host thread at
+ * a time and drives one GPU.
+ */
+#ifndef RTX_H
+#define RTX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RTX_OK = 0,
+    RTX_ERR_INVALID_ARG = -1,   /* null pointer, bad enum, bad range */
+    RTX_ERR_INVALID_SCENE = -2, /* a scene the reference would panic on (see rtx_set_scene) */
+    RTX_ERR_DEVICE = -3,        /* a HIP call failed */
+    RTX_ERR_NO_SCENE = -4,      /* render entry point called before rtx_set_scene */
+    RTX_ERR_UNSUPPORTED = -5,   /* combination of options not available */
+    RTX_ERR_NO_MEMORY = -6
+} rtx_status;
+
+/* FigureType, src/parser.rs:43-47 / src/objects/figures.rs:4-17 */
+typedef enum { RTX_PLANE = 0, RTX_ELLIPSOID = 1, RTX_BOX = 2 } rtx_kind;
+/* Material, src/objects/object.rs:5-9 */
+typedef enum { RTX_DIFFUSE = 0, RTX_METALLIC = 1, RTX_DIELECTRIC = 2 } rtx_material;
+
+/* One Object<PositionedFigure<_>>: src/objects/object.rs:11-17 and
+ * src/objects/figures.rs:19-23.  Defaults as in object.rs:19-27 / figures.rs:25-33:
+ * position 0, rotation (0,0,0,1), color 0, emission 0, diffuse. */
+typedef struct rtx_prim {
+    uint32_t kind;       /* rtx_kind */
+    float param[3];      /* plane normal (not normalised) | ellipsoid radii | box half-sizes */
+    float position[3];
+    float rotation[4];   /* unit quaternion x, y, z, w */
+    float color[3];
+    float emission[3];
+    uint32_t material;   /* rtx_material */
+    float ior;           /* used when material == RTX_DIELECTRIC */
+} rtx_prim;
+
+/* Scene, src/parser.rs:12-24, with Camera (src/camera.rs:6-12) flattened.
+ * cam_axis = the columns right, up, forward (src/parser.rs:64);
+ * tg_fov_x = tan(fov_x / 2), tg_fov_y = (height / width) * tg_fov_x (src/parser.rs:53-55).
+ * The lights list of the Scene (src/parser.rs:69-89) is derived inside the library. */
+typedef struct rtx_scene {
+    uint32_t width, height;
+    uint32_t ray_depth;
+    uint32_t n_samples;
+    float background[3];
+    float cam_pos[3];
+    float cam_axis[9];
+    float tg_fov_x, tg_fov_y;
+    uint32_t n_prims;
+    const rtx_prim *prims;
+} rtx_scene;
+
+typedef enum {
+    RTX_MODE_MEGAKERNEL = 0, /* one lane per pixel, sample and bounce loops in-kernel */
+    RTX_MODE_WAVEFRONT = 1   /* staged kernels over compacted ray queues */
+} rtx_mode;
+typedef enum {
+    RTX_ACCEL_AUTO = 0,      /* brute force up to RTX_MAX_LDS_PRIMS objects, BVH above */
+    RTX_ACCEL_BRUTE_LDS = 1, /* linear scan, object table staged in LDS */
+    RTX_ACCEL_BRUTE_SCALAR = 2, /* linear scan, object table read through the scalar cache */
+    RTX_ACCEL_BVH = 3        /* host-built BVH over ellipsoids and boxes + plane list */
+} rtx_accel;
+typedef enum {
+    RTX_RNG_PHILOX = 0, /* Philox4x32-10 block per (pixel, sample, slot), key = seed */
+    RTX_RNG_CONST = 1   /* every draw block returns const_words (zero-randomness shading) */
+} rtx_rng;
+
+#define RTX_MAX_LDS_PRIMS 512u
+
+typedef struct rtx_opts {
+    uint64_t seed;
+    uint32_t mode;           /* rtx_mode */
+    uint32_t accel;          /* rtx_accel */
+    uint32_t rng_mode;       /* rtx_rng */
+    uint32_t const_words[4];
+    int32_t device;          /* HIP device ordinal; -1 = the current device */
+    uint32_t collect_stats;  /* 1 = count path events (slower kernels; see rtx_get_stats) */
+} rtx_opts;
+
+/* Path events of the most recent render call, counted on the device when
+ * collect_stats = 1.  Used to turn a run into algorithmic FLOPs. */
+typedef struct rtx_stats {
+    uint64_t samples;          /* (pixel, step) iterations, src/main.rs:14-28 */
+    uint64_t rays;             /* closest-hit queries, src/trace.rs:16 */
+    uint64_t hits[3];          /* closest hits by rtx_kind */
+    uint64_t cosine_samples;   /* src/random.rs:33-53 */
+    uint64_t light_samples[3]; /* src/random.rs:73-81 by light kind */
+    uint64_t pdf_evals;        /* src/random.rs:143-152 */
+    uint64_t light_pdf[3];     /* per (pdf eval, light): 0 / 1 / 2 intersections found */
+    uint64_t diffuse_bounces;
+    uint64_t metallic_bounces;
+    uint64_t dielectric_bounces;
+    uint64_t prim_tests[3];    /* object intersect calls in closest-hit queries by kind */
+    uint64_t light_tests[3];   /* light intersect calls in light-pdf evaluation by kind */
+} rtx_stats;
+
+typedef struct rtx_ctx rtx_ctx;
+
+/* Context life cycle.  No counterpart in the reference (its state is the Scene). */
+int rtx_create(rtx_ctx **out, const rtx_opts *opts);
+void rtx_destroy(rtx_ctx *ctx);
+
+/* Validate, copy and upload a scene; derive the lights (src/parser.rs:69-89) and,
+ * when the accel option asks for it, build the BVH.  Replaces the hand-over of
+ * `Scene` from parse_scene to render (src/main.rs:37-38).
+ * RTX_ERR_INVALID_SCENE where the reference would panic: width/height 0, an
+ * emissive box with a half-size <= 0 (src/objects/sample.rs:30,46 gen_range on an empty
+ * range). */
+int rtx_set_scene(rtx_ctx *ctx, const rtx_scene *scene);
+
+/* Drop-in for `render(&mut scene)` (src/main.rs:13-31): renders scene->n_samples
+ * samples per pixel and writes the mean linear radiance to rgb (host memory,
+ * width*height*3 floats, row 0 = TOP row as src/image.rs:21-29 stores it). */
+int rtx_render(rtx_ctx *ctx, const rtx_scene *scene, float *rgb);
+
+/* The sample loop of src/main.rs:14 restricted to global sample indices
+ * [sample_first, sample_first + sample_count) of the scene given to
+ * rtx_set_scene.  Writes (not adds) the per-pixel SUM of radiance to d_sum, a
+ * DEVICE buffer of width*height*3 floats, asynchronously on hip_stream
+ * (a hipStream_t; NULL = the null stream).  Used to split samples over GPUs. */
+int rtx_render_samples(rtx_ctx *ctx, uint32_t sample_first, uint32_t sample_count,
+                       float *d_sum, void *hip_stream);
+
+/* d_rgb[i] = d_rgb[i] / divisor on the device: turns summed radiance into the
+ * mean that src/main.rs:26 maintains. */
+int rtx_divide(rtx_ctx *ctx, float *d_rgb, uint64_t n_floats, float divisor, void *hip_stream);
+
+/* Deterministic primary-visibility pass: one ray through every pixel centre
+ * (src/main.rs:19-21 with du = dv = 0.5) and its closest hit (src/trace.rs:102-121).
+ * Host output arrays of width*height entries (normal: *3), row 0 = top; any may
+ * be NULL.  hit_id = object index or -1. */
+int rtx_primary(rtx_ctx *ctx, const rtx_scene *scene, int32_t *hit_id, float *t,
+                float *normal, uint8_t *inside);
+
+/* Event counters of the last render on this context (needs collect_stats = 1). */
+int rtx_get_stats(rtx_ctx *ctx, rtx_stats *out);
+
+/* Milliseconds the device spent in the kernels of the last rtx_render /
+ * rtx_render_samples call, from HIP events on that call's stream.  Waits for
+ * the call to finish. */
+int rtx_last_kernel_ms(rtx_ctx *ctx, float *ms);
+
+/* Number of lights derived from the current scene, and their object indices. */
+int rtx_get_lights(rtx_ctx *ctx, int32_t *indices, int32_t capacity);
+
+/* Message for the calling thread's most recent error ("" if none). */
+const char *rtx_last_error(void);
+
+/* ABI version of this header: bumped on any layout or signature change. */
+uint32_t rtx_abi_version(void);
+#define RTX_ABI_VERSION 1u
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_H */

@@ -1,0 +1,247 @@
+"""ctypes binding of oracle/librt_oracle.so (the CPU oracle).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py, never by the raytracing_amd package.
+PARITY UNPINNED: see oracle/rt_oracle.h.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "librt_oracle.so")
+
+
+class orc_prim(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("param", C.c_float * 3), ("position", C.c_float * 3),
+                ("rotation", C.c_float * 4), ("color", C.c_float * 3), ("emission", C.c_float * 3),
+                ("material", C.c_uint32), ("ior", C.c_float)]
+
+
+class orc_scene(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("ray_depth", C.c_uint32),
+                ("n_samples", C.c_uint32), ("background", C.c_float * 3), ("cam_pos", C.c_float * 3),
+                ("cam_axis", C.c_float * 9), ("tg_fov_x", C.c_float), ("tg_fov_y", C.c_float),
+                ("n_prims", C.c_uint32), ("prims", C.POINTER(orc_prim))]
+
+
+class orc_opts(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("rng_mode", C.c_uint32), ("const_words", C.c_uint32 * 4),
+                ("order", C.c_uint32), ("sample_first", C.c_uint32), ("sample_count", C.c_uint32),
+                ("output_sum", C.c_uint32)]
+
+
+class orc_stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("hits", C.c_uint64 * 3),
+                ("cosine_samples", C.c_uint64), ("light_samples", C.c_uint64 * 3),
+                ("pdf_evals", C.c_uint64), ("light_pdf", C.c_uint64 * 3),
+                ("diffuse_bounces", C.c_uint64), ("metallic_bounces", C.c_uint64),
+                ("dielectric_bounces", C.c_uint64), ("prim_tests", C.c_uint64 * 3),
+                ("light_tests", C.c_uint64 * 3)]
+
+    def as_dict(self):
+        out = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            out[name] = list(v) if hasattr(v, "__len__") else int(v)
+        return out
+
+
+RNG_PHILOX, RNG_CONST = 0, 1
+ORDER_REFERENCE, ORDER_FORWARD = 0, 1
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = C.CDLL(_LIB_PATH)
+        fp = C.POINTER(C.c_float)
+        L.orc_render.restype = C.c_int
+        L.orc_render.argtypes = [C.POINTER(orc_scene), C.POINTER(orc_opts), fp, C.POINTER(orc_stats)]
+        L.orc_primary.restype = C.c_int
+        L.orc_primary.argtypes = [C.POINTER(orc_scene), C.POINTER(C.c_int32), fp, fp, C.POINTER(C.c_uint8)]
+        L.orc_closest_hit.restype = C.c_int
+        L.orc_closest_hit.argtypes = [C.POINTER(orc_scene), fp, fp, fp, fp, C.POINTER(C.c_int)]
+        L.orc_philox4x32_10.restype = None
+        L.orc_philox4x32_10.argtypes = [C.POINTER(C.c_uint32)] * 3
+        L.orc_sincos.restype = None
+        L.orc_sincos.argtypes = [C.c_float, fp, fp]
+        L.orc_camera_ray.restype = None
+        L.orc_camera_ray.argtypes = [C.POINTER(orc_scene), C.c_float, C.c_float, fp, fp]
+        L.orc_figure_intersect.restype = C.c_int
+        L.orc_figure_intersect.argtypes = [C.c_uint32, fp, fp, fp, fp, fp, C.POINTER(C.c_int)]
+        L.orc_reflect.restype = None
+        L.orc_reflect.argtypes = [fp] * 5
+        L.orc_refract.restype = C.c_int
+        L.orc_refract.argtypes = [fp, fp, fp, C.c_float, fp, fp]
+        L.orc_schlick.restype = C.c_float
+        L.orc_schlick.argtypes = [C.c_float, C.c_float]
+        L.orc_cosine_sample.restype = None
+        L.orc_cosine_sample.argtypes = [fp, C.c_uint32, C.c_uint32, fp]
+        L.orc_light_sample.restype = None
+        L.orc_light_sample.argtypes = [C.POINTER(orc_scene), C.c_uint32, C.POINTER(C.c_uint32), fp]
+        L.orc_mis_pdf.restype = C.c_float
+        L.orc_mis_pdf.argtypes = [C.POINTER(orc_scene), fp, fp, fp]
+        L.orc_light_pdf.restype = C.c_float
+        L.orc_light_pdf.argtypes = [C.POINTER(orc_scene), fp, fp]
+        L.orc_lights.restype = C.c_int
+        L.orc_lights.argtypes = [C.POINTER(orc_scene), C.POINTER(C.c_int32), C.c_int]
+        L.orc_color_correction.restype = None
+        L.orc_color_correction.argtypes = [fp, C.c_uint64]
+        L.orc_to_bytes.restype = None
+        L.orc_to_bytes.argtypes = [fp, C.c_uint64, C.POINTER(C.c_uint8)]
+        _lib = L
+    return _lib
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def c_scene(scene):
+    """(orc_scene, keep-alive) from a raytracing_amd.scene.Scene (used as a data container)."""
+    return scene.to_ctypes(prim_type=orc_prim, scene_type=orc_scene)
+
+
+def render(scene, seed=1, order=ORDER_REFERENCE, rng_mode=RNG_PHILOX, const_words=(0, 0, 0, 0),
+           sample_first=0, sample_count=0, output_sum=False, want_stats=False):
+    s, keep = c_scene(scene)
+    o = orc_opts()
+    o.seed, o.rng_mode, o.order = seed, rng_mode, order
+    o.const_words[:] = const_words
+    o.sample_first, o.sample_count, o.output_sum = sample_first, sample_count, int(output_sum)
+    out = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
+    st = orc_stats()
+    rc = lib().orc_render(C.byref(s), C.byref(o), _fp(out), C.byref(st) if want_stats else None)
+    if rc != 0:
+        raise RuntimeError(f"orc_render failed: {rc}")
+    return (out, st.as_dict()) if want_stats else out
+
+
+def primary(scene):
+    s, keep = c_scene(scene)
+    n = scene.width * scene.height
+    ids = np.zeros(n, dtype=np.int32)
+    t = np.zeros(n, dtype=np.float32)
+    nrm = np.zeros((n, 3), dtype=np.float32)
+    ins = np.zeros(n, dtype=np.uint8)
+    rc = lib().orc_primary(C.byref(s), ids.ctypes.data_as(C.POINTER(C.c_int32)), _fp(t), _fp(nrm),
+                           ins.ctypes.data_as(C.POINTER(C.c_uint8)))
+    if rc != 0:
+        raise RuntimeError(f"orc_primary failed: {rc}")
+    shp = (scene.height, scene.width)
+    return ids.reshape(shp), t.reshape(shp), nrm.reshape(shp + (3,)), ins.reshape(shp)
+
+
+def closest_hit(scene, origin, direction):
+    s, keep = c_scene(scene)
+    t = C.c_float()
+    n = (C.c_float * 3)()
+    ins = C.c_int()
+    idx = lib().orc_closest_hit(C.byref(s), _f3(origin), _f3(direction), C.byref(t), n, C.byref(ins))
+    return idx, t.value, tuple(n), bool(ins.value)
+
+
+def camera_ray(scene, u, v):
+    s, keep = c_scene(scene)
+    o = (C.c_float * 3)()
+    d = (C.c_float * 3)()
+    lib().orc_camera_ray(C.byref(s), u, v, o, d)
+    return tuple(o), tuple(d)
+
+
+def philox(ctr, key):
+    c = (C.c_uint32 * 4)(*ctr)
+    k = (C.c_uint32 * 2)(*key)
+    out = (C.c_uint32 * 4)()
+    lib().orc_philox4x32_10(c, k, out)
+    return tuple(out)
+
+
+def sincos(x):
+    s, c = C.c_float(), C.c_float()
+    lib().orc_sincos(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def figure_intersect(kind, param, origin, direction):
+    t = C.c_float()
+    n = (C.c_float * 3)()
+    ins = C.c_int()
+    hit = lib().orc_figure_intersect(kind, _f3(param), _f3(origin), _f3(direction), C.byref(t), n, C.byref(ins))
+    return (t.value, tuple(n), bool(ins.value)) if hit else None
+
+
+def reflect(direction, point, normal):
+    o, d = (C.c_float * 3)(), (C.c_float * 3)()
+    lib().orc_reflect(_f3(direction), _f3(point), _f3(normal), o, d)
+    return tuple(o), tuple(d)
+
+
+def refract(direction, point, normal, eta):
+    o, d = (C.c_float * 3)(), (C.c_float * 3)()
+    ok = lib().orc_refract(_f3(direction), _f3(point), _f3(normal), eta, o, d)
+    return (tuple(o), tuple(d)) if ok else None
+
+
+def schlick(eta, cosv):
+    return lib().orc_schlick(eta, cosv)
+
+
+def cosine_sample(n, w_theta, w_r):
+    out = (C.c_float * 3)()
+    lib().orc_cosine_sample(_f3(n), w_theta, w_r, out)
+    return tuple(out)
+
+
+def light_sample(scene, prim_index, words):
+    s, keep = c_scene(scene)
+    out = (C.c_float * 3)()
+    lib().orc_light_sample(C.byref(s), prim_index, (C.c_uint32 * 4)(*words), out)
+    return tuple(out)
+
+
+def mis_pdf(scene, p, n, d):
+    s, keep = c_scene(scene)
+    return lib().orc_mis_pdf(C.byref(s), _f3(p), _f3(n), _f3(d))
+
+
+def light_pdf(scene, p, d):
+    s, keep = c_scene(scene)
+    return lib().orc_light_pdf(C.byref(s), _f3(p), _f3(d))
+
+
+def lights(scene):
+    s, keep = c_scene(scene)
+    buf = (C.c_int32 * max(1, len(scene.prims)))()
+    n = lib().orc_lights(C.byref(s), buf, len(scene.prims))
+    return list(buf[:n])
+
+
+def color_correction(rgb):
+    out = np.ascontiguousarray(rgb, dtype=np.float32).copy()
+    lib().orc_color_correction(_fp(out), out.size)
+    return out
+
+
+def to_bytes(rgb):
+    a = np.ascontiguousarray(rgb, dtype=np.float32)
+    out = np.zeros(a.shape, dtype=np.uint8)
+    lib().orc_to_bytes(_fp(a), a.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
