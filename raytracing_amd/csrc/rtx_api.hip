@@ -1,0 +1,452 @@
+// rtx_api.hip -- the C ABI of include/rtx.h: context, scene upload, launches.
+//
+// Replaces the call `render(&mut scene)` of src/main.rs:38 and the Scene hand-over of
+// src/main.rs:37; the lights list is derived here by the rule of src/parser.rs:69-89.
+#include "../../include/rtx.h"
+#include "rtx_bvh.h"
+#include "rtx_device.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(e_ == hipErrorOutOfMemory ? RTX_ERR_NO_MEMORY : RTX_ERR_DEVICE, "%s: %s",  \
+                        #expr, hipGetErrorString(e_));                                             \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+        if (dev != prev && hipSetDevice(dev) != hipSuccess) ok = false;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace
+
+struct rtx_ctx {
+    rtx_opts opts{};
+    int device = 0;
+    // host copy of the scene
+    bool have_scene = false;
+    rtx_scene scene{};
+    std::vector<rtx_prim> prims;
+    std::vector<int32_t> lights;
+    int src = rtx::kSrcLds;
+    // device scene block
+    void *d_scene = nullptr;
+    size_t d_scene_bytes = 0;
+    rtx::RenderParams params{};
+    // scratch owned by the context
+    float *d_image = nullptr;
+    size_t d_image_floats = 0;
+    unsigned long long *d_stats = nullptr;
+    rtx_stats stats{};
+    bool stats_valid = false;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    bool timed = false;
+};
+
+namespace {
+
+void free_scene(rtx_ctx *c)
+{
+    if (c->d_scene) (void)hipFree(c->d_scene);
+    c->d_scene = nullptr;
+    c->d_scene_bytes = 0;
+    c->have_scene = false;
+}
+
+size_t align16(size_t x) { return (x + 15u) & ~(size_t)15u; }
+
+// src/parser.rs:69-89
+void derive_lights(const std::vector<rtx_prim> &prims, std::vector<int32_t> &out)
+{
+    out.clear();
+    for (size_t i = 0; i < prims.size(); ++i) {
+        const float *e = prims[i].emission;
+        float l2 = (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2];
+        if (l2 == 0.0f) continue;
+        if (prims[i].kind == RTX_PLANE) continue;
+        out.push_back((int32_t)i);
+    }
+}
+
+int validate_scene(const rtx_scene *s)
+{
+    if (!s) return fail(RTX_ERR_INVALID_ARG, "scene is null");
+    if (s->width == 0 || s->height == 0) return fail(RTX_ERR_INVALID_SCENE, "image dimensions must be positive");
+    if ((uint64_t)s->width * s->height > 0x7fffffffull / 3u)
+        return fail(RTX_ERR_INVALID_SCENE, "image too large: %u x %u", s->width, s->height);
+    if (s->n_prims > 0 && !s->prims) return fail(RTX_ERR_INVALID_ARG, "prims is null");
+    if (s->n_prims > (1u << 24)) return fail(RTX_ERR_INVALID_SCENE, "too many objects: %u", s->n_prims);
+    for (uint32_t i = 0; i < s->n_prims; ++i) {
+        const rtx_prim &p = s->prims[i];
+        if (p.kind > RTX_BOX) return fail(RTX_ERR_INVALID_SCENE, "object %u: unknown kind %u", i, p.kind);
+        if (p.material > RTX_DIELECTRIC)
+            return fail(RTX_ERR_INVALID_SCENE, "object %u: unknown material %u", i, p.material);
+        const float *e = p.emission;
+        bool emissive = ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) != 0.0f;
+        if (emissive && p.kind == RTX_BOX) {
+            // sampling this light draws from [-s, s) per axis and from [0, area): the
+            // reference panics on an empty range
+            for (int k = 0; k < 3; ++k)
+                if (!(p.param[k] > 0.0f))
+                    return fail(RTX_ERR_INVALID_SCENE, "object %u: emissive box needs positive half-sizes", i);
+        }
+    }
+    return RTX_OK;
+}
+
+int upload_scene(rtx_ctx *c)
+{
+    const size_t n = c->prims.size();
+    const size_t nl = c->lights.size();
+    const size_t geom_bytes = align16(n * 3 * sizeof(float4));
+    const size_t mat_bytes = align16(n * 2 * sizeof(float4));
+    const size_t light_bytes = align16(nl * sizeof(int32_t));
+
+    rtx::BvhHost bvh;
+    const bool want_bvh = c->src == rtx::kSrcBvh;
+    if (want_bvh) rtx::build_bvh(c->prims.data(), (uint32_t)n, bvh);
+    const size_t node_bytes = align16(bvh.nodes.size() * sizeof(float4));
+    const size_t pidx_bytes = align16(bvh.prim_index.size() * sizeof(int32_t));
+    const size_t plane_bytes = align16(bvh.planes.size() * sizeof(int32_t));
+
+    const size_t total = geom_bytes + mat_bytes + light_bytes + node_bytes + pidx_bytes + plane_bytes + 16;
+    std::vector<unsigned char> host(total, 0);
+    float4 *geom = reinterpret_cast<float4 *>(host.data());
+    float4 *mat = reinterpret_cast<float4 *>(host.data() + geom_bytes);
+    int32_t *lights = reinterpret_cast<int32_t *>(host.data() + geom_bytes + mat_bytes);
+    for (size_t i = 0; i < n; ++i) {
+        const rtx_prim &p = c->prims[i];
+        int32_t kind = (int32_t)p.kind, material = (int32_t)p.material;
+        float kind_bits, mat_bits;
+        std::memcpy(&kind_bits, &kind, 4);
+        std::memcpy(&mat_bits, &material, 4);
+        geom[3 * i + 0] = make_float4(p.rotation[0], p.rotation[1], p.rotation[2], p.rotation[3]);
+        geom[3 * i + 1] = make_float4(p.position[0], p.position[1], p.position[2], kind_bits);
+        geom[3 * i + 2] = make_float4(p.param[0], p.param[1], p.param[2], 0.0f);
+        mat[2 * i + 0] = make_float4(p.color[0], p.color[1], p.color[2], mat_bits);
+        mat[2 * i + 1] = make_float4(p.emission[0], p.emission[1], p.emission[2], p.ior);
+    }
+    for (size_t i = 0; i < nl; ++i) lights[i] = c->lights[i];
+    size_t off_nodes = geom_bytes + mat_bytes + light_bytes;
+    size_t off_pidx = off_nodes + node_bytes, off_planes = off_pidx + pidx_bytes;
+    if (!bvh.nodes.empty()) std::memcpy(host.data() + off_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(float4));
+    if (!bvh.prim_index.empty())
+        std::memcpy(host.data() + off_pidx, bvh.prim_index.data(), bvh.prim_index.size() * sizeof(int32_t));
+    if (!bvh.planes.empty())
+        std::memcpy(host.data() + off_planes, bvh.planes.data(), bvh.planes.size() * sizeof(int32_t));
+
+    if (c->d_scene_bytes < total) {
+        if (c->d_scene) (void)hipFree(c->d_scene);
+        c->d_scene = nullptr;
+        c->d_scene_bytes = 0;
+        HIP_TRY(hipMalloc(&c->d_scene, total));
+        c->d_scene_bytes = total;
+    }
+    HIP_TRY(hipMemcpy(c->d_scene, host.data(), total, hipMemcpyHostToDevice));
+
+    unsigned char *base = static_cast<unsigned char *>(c->d_scene);
+    rtx::RenderParams &P = c->params;
+    std::memset(&P, 0, sizeof(P));
+    P.geom = reinterpret_cast<const float4 *>(base);
+    P.mat = reinterpret_cast<const float4 *>(base + geom_bytes);
+    P.lights = reinterpret_cast<const int32_t *>(base + geom_bytes + mat_bytes);
+    P.n_prims = (uint32_t)n;
+    P.n_lights = (uint32_t)nl;
+    const rtx_scene &s = c->scene;
+    P.width = s.width;
+    P.height = s.height;
+    P.ray_depth = s.ray_depth;
+    std::memcpy(P.bg, s.background, sizeof(P.bg));
+    std::memcpy(P.cam_pos, s.cam_pos, sizeof(P.cam_pos));
+    std::memcpy(P.cam_axis, s.cam_axis, sizeof(P.cam_axis));
+    P.tg_fov_x = s.tg_fov_x;
+    P.tg_fov_y = s.tg_fov_y;
+    P.seed_lo = (uint32_t)c->opts.seed;
+    P.seed_hi = (uint32_t)(c->opts.seed >> 32);
+    P.rng_const = c->opts.rng_mode == RTX_RNG_CONST ? 1u : 0u;
+    std::memcpy(P.const_words, c->opts.const_words, sizeof(P.const_words));
+    P.bvh.nodes = reinterpret_cast<const float4 *>(base + off_nodes);
+    P.bvh.prim_index = reinterpret_cast<const int32_t *>(base + off_pidx);
+    P.bvh.planes = reinterpret_cast<const int32_t *>(base + off_planes);
+    P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / 2);
+    P.bvh.n_planes = (uint32_t)bvh.planes.size();
+    return RTX_OK;
+}
+
+int ensure_image(rtx_ctx *c, size_t floats)
+{
+    if (c->d_image_floats >= floats) return RTX_OK;
+    if (c->d_image) (void)hipFree(c->d_image);
+    c->d_image = nullptr;
+    c->d_image_floats = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_image), floats * sizeof(float)));
+    c->d_image_floats = floats;
+    return RTX_OK;
+}
+
+void stats_from_counters(const rtx_ctx *c, const unsigned long long *v, rtx_stats *s)
+{
+    std::memset(s, 0, sizeof(*s));
+    s->samples = v[rtx::C_SAMPLES];
+    s->rays = v[rtx::C_RAYS];
+    s->hits[0] = v[rtx::C_HIT_PLANE];
+    s->hits[1] = v[rtx::C_HIT_ELLIPSOID];
+    s->hits[2] = v[rtx::C_HIT_BOX];
+    s->cosine_samples = v[rtx::C_COSINE];
+    s->light_samples[1] = v[rtx::C_LSAMPLE_ELLIPSOID];
+    s->light_samples[2] = v[rtx::C_LSAMPLE_BOX];
+    s->pdf_evals = v[rtx::C_PDF_EVALS];
+    s->light_pdf[0] = v[rtx::C_LPDF_0];
+    s->light_pdf[1] = v[rtx::C_LPDF_1];
+    s->light_pdf[2] = v[rtx::C_LPDF_2];
+    s->diffuse_bounces = v[rtx::C_DIFFUSE];
+    s->metallic_bounces = v[rtx::C_METALLIC];
+    s->dielectric_bounces = v[rtx::C_DIELECTRIC];
+    s->light_tests[1] = v[rtx::C_LTEST_ELLIPSOID];
+    s->light_tests[2] = v[rtx::C_LTEST_BOX];
+    // a brute-force closest-hit query tests every object once
+    if (c->src != rtx::kSrcBvh) {
+        uint64_t per_kind[3] = {0, 0, 0};
+        for (const rtx_prim &p : c->prims) per_kind[p.kind]++;
+        for (int k = 0; k < 3; ++k) s->prim_tests[k] = s->rays * per_kind[k];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t rtx_abi_version(void) { return RTX_ABI_VERSION; }
+
+const char *rtx_last_error(void) { return g_last_error.c_str(); }
+
+int rtx_create(rtx_ctx **out, const rtx_opts *opts)
+{
+    if (!out || !opts) return fail(RTX_ERR_INVALID_ARG, "rtx_create: null argument");
+    *out = nullptr;
+    if (opts->mode > RTX_MODE_WAVEFRONT) return fail(RTX_ERR_INVALID_ARG, "unknown mode %u", opts->mode);
+    if (opts->accel > RTX_ACCEL_BVH) return fail(RTX_ERR_INVALID_ARG, "unknown accel %u", opts->accel);
+    if (opts->rng_mode > RTX_RNG_CONST) return fail(RTX_ERR_INVALID_ARG, "unknown rng_mode %u", opts->rng_mode);
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (n_dev <= 0) return fail(RTX_ERR_DEVICE, "no HIP device visible");
+    int dev = opts->device;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= n_dev) return fail(RTX_ERR_INVALID_ARG, "device %d out of range (%d visible)", dev, n_dev);
+    rtx_ctx *c = new (std::nothrow) rtx_ctx();
+    if (!c) return fail(RTX_ERR_NO_MEMORY, "out of host memory");
+    c->opts = *opts;
+    c->device = dev;
+    DeviceGuard g(dev);
+    if (!g.ok) { delete c; return fail(RTX_ERR_DEVICE, "cannot select device %d", dev); }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_stats), rtx::C_COUNT * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
+    if (e != hipSuccess) {
+        rtx_destroy(c);
+        return fail(RTX_ERR_DEVICE, "context set-up: %s", hipGetErrorString(e));
+    }
+    *out = c;
+    return RTX_OK;
+}
+
+void rtx_destroy(rtx_ctx *c)
+{
+    if (!c) return;
+    DeviceGuard g(c->device);
+    free_scene(c);
+    if (c->d_image) (void)hipFree(c->d_image);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    delete c;
+}
+
+int rtx_set_scene(rtx_ctx *c, const rtx_scene *s)
+{
+    if (!c) return fail(RTX_ERR_INVALID_ARG, "ctx is null");
+    int rc = validate_scene(s);
+    if (rc != RTX_OK) return rc;
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", c->device);
+    c->have_scene = false;
+    c->scene = *s;
+    c->prims.assign(s->prims, s->prims + s->n_prims);
+    c->scene.prims = nullptr;
+    derive_lights(c->prims, c->lights);
+    switch (c->opts.accel) {
+    case RTX_ACCEL_AUTO: c->src = s->n_prims <= RTX_MAX_LDS_PRIMS ? rtx::kSrcLds : rtx::kSrcBvh; break;
+    case RTX_ACCEL_BRUTE_LDS:
+        if (s->n_prims > RTX_MAX_LDS_PRIMS)
+            return fail(RTX_ERR_UNSUPPORTED, "%u objects exceed the LDS table limit of %u", s->n_prims,
+                        RTX_MAX_LDS_PRIMS);
+        c->src = rtx::kSrcLds;
+        break;
+    case RTX_ACCEL_BRUTE_SCALAR: c->src = rtx::kSrcScalar; break;
+    default: c->src = rtx::kSrcBvh; break;
+    }
+    if (c->opts.mode == RTX_MODE_WAVEFRONT && c->src == rtx::kSrcBvh)
+        return fail(RTX_ERR_UNSUPPORTED, "the wavefront variant scans the object table; BVH is megakernel-only");
+    rc = upload_scene(c);
+    if (rc != RTX_OK) return rc;
+    c->have_scene = true;
+    return RTX_OK;
+}
+
+int rtx_render_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream)
+{
+    if (!c || !d_sum) return fail(RTX_ERR_INVALID_ARG, "rtx_render_samples: null argument");
+    if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_set_scene has not been called");
+    if ((uint64_t)sample_first + sample_count > 0xffffffffull)
+        return fail(RTX_ERR_INVALID_ARG, "sample range overflows 32 bits");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", c->device);
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    rtx::RenderParams P = c->params;
+    P.sample_first = sample_first;
+    P.sample_count = sample_count;
+    P.out_sum = d_sum;
+    const bool stats = c->opts.collect_stats != 0;
+    P.stats = stats ? c->d_stats : nullptr;
+    c->stats_valid = false;
+    if (stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, rtx::C_COUNT * sizeof(unsigned long long), stream));
+    HIP_TRY(hipEventRecord(c->ev_start, stream));
+    if (c->opts.mode == RTX_MODE_WAVEFRONT) {
+        return fail(RTX_ERR_UNSUPPORTED, "wavefront mode is not available in this build");
+    } else {
+        HIP_TRY(rtx::launch_megakernel(P, c->src, stats, stream));
+    }
+    HIP_TRY(hipEventRecord(c->ev_stop, stream));
+    c->timed = true;
+    if (stats) {
+        unsigned long long v[rtx::C_COUNT];
+        HIP_TRY(hipMemcpyAsync(v, c->d_stats, sizeof(v), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        stats_from_counters(c, v, &c->stats);
+        c->stats_valid = true;
+    }
+    return RTX_OK;
+}
+
+int rtx_divide(rtx_ctx *c, float *d_rgb, uint64_t n_floats, float divisor, void *hip_stream)
+{
+    if (!c || !d_rgb) return fail(RTX_ERR_INVALID_ARG, "rtx_divide: null argument");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", c->device);
+    HIP_TRY(rtx::launch_divide(d_rgb, n_floats, divisor, static_cast<hipStream_t>(hip_stream)));
+    return RTX_OK;
+}
+
+int rtx_render(rtx_ctx *c, const rtx_scene *s, float *rgb)
+{
+    if (!c || !rgb) return fail(RTX_ERR_INVALID_ARG, "rtx_render: null argument");
+    int rc = rtx_set_scene(c, s);
+    if (rc != RTX_OK) return rc;
+    DeviceGuard g(c->device);
+    const size_t floats = (size_t)s->width * s->height * 3u;
+    rc = ensure_image(c, floats);
+    if (rc != RTX_OK) return rc;
+    if (s->n_samples == 0) {
+        // src/main.rs:14: zero iterations leave the zero-initialised image (src/image.rs:17)
+        std::memset(rgb, 0, floats * sizeof(float));
+        return RTX_OK;
+    }
+    rc = rtx_render_samples(c, 0, s->n_samples, c->d_image, nullptr);
+    if (rc != RTX_OK) return rc;
+    rc = rtx_divide(c, c->d_image, floats, (float)s->n_samples, nullptr);
+    if (rc != RTX_OK) return rc;
+    HIP_TRY(hipMemcpy(rgb, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_primary(rtx_ctx *c, const rtx_scene *s, int32_t *hit_id, float *t, float *normal, uint8_t *inside)
+{
+    if (!c) return fail(RTX_ERR_INVALID_ARG, "ctx is null");
+    int rc = rtx_set_scene(c, s);
+    if (rc != RTX_OK) return rc;
+    DeviceGuard g(c->device);
+    const size_t n = (size_t)s->width * s->height;
+    // one device block: ids | t | normal | inside
+    const size_t bytes = n * 4 + n * 4 + n * 12 + align16(n);
+    void *d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    unsigned char *b = static_cast<unsigned char *>(d);
+    rtx::PrimaryParams out;
+    out.hit_id = reinterpret_cast<int32_t *>(b);
+    out.t = reinterpret_cast<float *>(b + n * 4);
+    out.normal = reinterpret_cast<float *>(b + n * 8);
+    out.inside = reinterpret_cast<uint8_t *>(b + n * 20);
+    hipError_t e = rtx::launch_primary(c->params, out, c->src, nullptr);
+    if (e == hipSuccess && hit_id) e = hipMemcpy(hit_id, out.hit_id, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && t) e = hipMemcpy(t, out.t, n * 4, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && normal) e = hipMemcpy(normal, out.normal, n * 12, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && inside) e = hipMemcpy(inside, out.inside, n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RTX_ERR_DEVICE, "primary pass: %s", hipGetErrorString(e));
+    return RTX_OK;
+}
+
+int rtx_get_stats(rtx_ctx *c, rtx_stats *out)
+{
+    if (!c || !out) return fail(RTX_ERR_INVALID_ARG, "rtx_get_stats: null argument");
+    if (!c->stats_valid) return fail(RTX_ERR_UNSUPPORTED, "no statistics: create the context with collect_stats = 1");
+    *out = c->stats;
+    return RTX_OK;
+}
+
+int rtx_last_kernel_ms(rtx_ctx *c, float *ms)
+{
+    if (!c || !ms) return fail(RTX_ERR_INVALID_ARG, "rtx_last_kernel_ms: null argument");
+    if (!c->timed) return fail(RTX_ERR_NO_SCENE, "nothing has been rendered yet");
+    DeviceGuard g(c->device);
+    HIP_TRY(hipEventSynchronize(c->ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    return RTX_OK;
+}
+
+int rtx_get_lights(rtx_ctx *c, int32_t *indices, int32_t capacity)
+{
+    if (!c) return fail(RTX_ERR_INVALID_ARG, "ctx is null");
+    if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_set_scene has not been called");
+    int32_t n = (int32_t)c->lights.size();
+    for (int32_t i = 0; i < n && i < capacity && indices; ++i) indices[i] = c->lights[i];
+    return n;
+}
+
+}  // extern "C"

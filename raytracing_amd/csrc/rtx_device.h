@@ -1,0 +1,70 @@
+// rtx_device.h -- data shared between the host side of librtx and its kernels.
+//
+// Device scene layout (one hipMalloc block, all arrays 16-byte aligned):
+//   geom[3*i+0] = rotation quaternion (x, y, z, w)          \  the 48 bytes a closest-hit
+//   geom[3*i+1] = position xyz, kind (int bits) in w          > scan reads per object
+//   geom[3*i+2] = param xyz (normal | radii | half-sizes), 0 /
+//   mat[2*i+0]  = color rgb, material (int bits) in w        \  the 32 bytes shading reads
+//   mat[2*i+1]  = emission rgb, ior in w                     /  for the object that was hit
+//   lights[k]   = object index of light k (emissive ellipsoids and boxes, object order)
+// The scan data and the shading data are separate arrays so that the scan streams 48
+// contiguous bytes per object and never touches colours.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtx {
+
+enum : int { kPlane = 0, kEllipsoid = 1, kBox = 2 };
+enum : int { kDiffuse = 0, kMetallic = 1, kDielectric = 2 };
+
+// event counters kept per lane when statistics are requested
+enum : int {
+    C_SAMPLES = 0, C_RAYS, C_HIT_PLANE, C_HIT_ELLIPSOID, C_HIT_BOX, C_COSINE,
+    C_LSAMPLE_ELLIPSOID, C_LSAMPLE_BOX, C_PDF_EVALS, C_LPDF_0, C_LPDF_1, C_LPDF_2,
+    C_DIFFUSE, C_METALLIC, C_DIELECTRIC, C_LTEST_ELLIPSOID, C_LTEST_BOX, C_COUNT
+};
+
+struct BvhView {
+    const float4 *nodes;   // 2 float4 per node, see rtx_bvh.h
+    const int32_t *prim_index; // leaf slots -> object index
+    const int32_t *planes; // objects that are tested for every ray
+    uint32_t n_nodes, n_planes;
+};
+
+// kernel parameters: passed by value, so every field sits in scalar registers
+struct RenderParams {
+    const float4 *geom;
+    const float4 *mat;
+    const int32_t *lights;
+    uint32_t n_prims, n_lights;
+    uint32_t width, height, ray_depth;
+    uint32_t sample_first, sample_count;
+    float bg[3];
+    float cam_pos[3];
+    float cam_axis[9]; // columns right, up, forward
+    float tg_fov_x, tg_fov_y;
+    uint32_t seed_lo, seed_hi;
+    uint32_t rng_const;     // 1: every draw block = const_words
+    uint32_t const_words[4];
+    float *out_sum;         // width*height*3, row 0 = top
+    unsigned long long *stats; // C_COUNT counters or nullptr
+    BvhView bvh;
+};
+
+struct PrimaryParams {
+    int32_t *hit_id;
+    float *t;
+    float *normal;
+    uint8_t *inside;
+};
+
+// launchers implemented in the .hip files
+enum : int { kSrcLds = 0, kSrcScalar = 1, kSrcBvh = 2 };
+hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, hipStream_t stream);
+hipError_t launch_primary(const RenderParams &p, const PrimaryParams &out, int src, hipStream_t stream);
+hipError_t launch_divide(float *d, uint64_t n, float divisor, hipStream_t stream);
+size_t scene_lds_bytes(uint32_t n_prims, uint32_t n_lights);
+
+}  // namespace rtx

@@ -1,0 +1,206 @@
+// rtx_kernels.hip -- megakernel path tracer and the deterministic primary pass (gfx950).
+//
+// Work decomposition (replaces the serial loop nest of src/main.rs:13-31):
+//   * one lane per pixel; a wave64 owns an 8x8 pixel tile, a 256-thread workgroup four tiles;
+//   * the sample loop (main.rs:14) and the bounce recursion (trace.rs:11-71, one child per
+//     call, so a loop) are flattened into ONE loop per lane whose iteration is a path
+//     segment: closest hit, then scatter.  A lane whose path ends starts its next sample in
+//     the same iteration, so every lane of the wave stays busy until its pixel is finished
+//     and the closest-hit scan -- the dominant cost -- always runs with a full exec mask;
+//   * the object index of the scan is wave-uniform: table reads are LDS broadcasts
+//     (kSrcLds: table staged once per workgroup) or scalar loads (kSrcScalar);
+//   * each lane keeps its pixel's radiance sum in registers and stores 12 bytes once.
+#include "rtx_trace.hpp"
+#include "rtx_bvh_traverse.hpp"
+
+namespace rtx {
+
+extern __shared__ float4 rtx_smem[];
+
+size_t scene_lds_bytes(uint32_t n_prims, uint32_t n_lights)
+{
+    size_t b = (size_t)n_prims * 5u * sizeof(float4) + (size_t)n_lights * sizeof(int32_t);
+    return (b + 15u) & ~(size_t)15u;
+}
+
+// copies the object table into LDS; every thread of the workgroup must call it
+RTX_DEV Table stage_table_lds(const RenderParams &P)
+{
+    const uint32_t ng = 3u * P.n_prims, nm = 2u * P.n_prims;
+    for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) rtx_smem[i] = P.geom[i];
+    for (uint32_t i = threadIdx.x; i < nm; i += blockDim.x) rtx_smem[ng + i] = P.mat[i];
+    int32_t *sl = reinterpret_cast<int32_t *>(rtx_smem + ng + nm);
+    for (uint32_t i = threadIdx.x; i < P.n_lights; i += blockDim.x) sl[i] = P.lights[i];
+    __syncthreads();
+    Table t;
+    t.geom = rtx_smem;
+    t.mat = rtx_smem + ng;
+    t.lights = sl;
+    t.n_prims = P.n_prims;
+    t.n_lights = P.n_lights;
+    return t;
+}
+RTX_DEV Table global_table(const RenderParams &P)
+{
+    Table t;
+    t.geom = P.geom;
+    t.mat = P.mat;
+    t.lights = P.lights;
+    t.n_prims = P.n_prims;
+    t.n_lights = P.n_lights;
+    return t;
+}
+
+// wave -> 8x8 tile, lane -> pixel inside it; rows counted from the top of the image
+RTX_DEV bool lane_pixel(const RenderParams &P, uint32_t &px, uint32_t &py)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const uint32_t tiles_x = (P.width + 7u) >> 3;
+    px = (tile % tiles_x) * 8u + (lane & 7u);
+    py = (tile / tiles_x) * 8u + (lane >> 3);
+    return px < P.width && py < P.height;
+}
+
+template <int SRC>
+RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, float &t)
+{
+    if constexpr (SRC == kSrcBvh) return closest_hit_bvh(P.bvh, tab, o, d, t);
+    else return closest_hit_scan<true>(tab, o, d, t);
+}
+
+template <int SRC, bool STATS>
+__global__ void __launch_bounds__(256) k_megakernel(const RenderParams P)
+{
+    Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
+    uint32_t px, py;
+    if (!lane_pixel(P, px, py)) return;
+    const uint32_t pixel = py * P.width + px;
+    const uint32_t pi = px, pj = P.height - 1u - py;
+
+    Counters<STATS> cnt;
+    cnt.clear();
+    const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
+    V3 sum = v3(0.0f, 0.0f, 0.0f);
+    Path p;
+    uint32_t s = P.sample_first;
+    const uint32_t s_end = P.sample_first + P.sample_count;
+    bool fresh = true;
+    while (s < s_end) {
+        if (fresh) {
+            uint4 w = draw_block(P, pixel, s, 0u);
+            camera_ray(P, pi, pj, u24(w.x), u24(w.y), p.o, p.d);
+            p.T = v3(1.0f, 1.0f, 1.0f);
+            p.L = v3(0.0f, 0.0f, 0.0f);
+            p.depth = 0;
+            fresh = false;
+            cnt.template add<C_SAMPLES>();
+        }
+        cnt.template add<C_RAYS>();
+        float t;
+        int idx = closest_hit<SRC>(P, tab, p.o, p.d, t);
+        bool done;
+        if (idx < 0) {
+            p.L = p.L + cmul(p.T, bg);
+            done = true;
+        } else {
+            if constexpr (STATS) {
+                int kind = __float_as_int(tab.geom[3 * idx + 1].w);
+                cnt.template add<C_HIT_PLANE>(kind == kPlane);
+                cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
+                cnt.template add<C_HIT_BOX>(kind == kBox);
+            }
+            done = scatter<STATS>(P, tab, p, idx, t, pixel, s, cnt);
+        }
+        if (done) {
+            sum = sum + p.L;
+            s += 1;
+            fresh = true;
+        }
+    }
+    float *out = P.out_sum + 3ull * pixel;
+    out[0] = sum.x;
+    out[1] = sum.y;
+    out[2] = sum.z;
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < C_COUNT; ++i)
+            if (cnt.v[i]) atomicAdd(&P.stats[i], (unsigned long long)cnt.v[i]);
+    }
+}
+
+template <int SRC>
+__global__ void __launch_bounds__(256) k_primary(const RenderParams P, const PrimaryParams out)
+{
+    Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
+    uint32_t px, py;
+    if (!lane_pixel(P, px, py)) return;
+    const uint32_t pixel = py * P.width + px;
+    V3 o, d;
+    camera_ray(P, px, P.height - 1u - py, 0.5f, 0.5f, o, d);
+    float t;
+    int idx = closest_hit<SRC>(P, tab, o, d, t);
+    Hit h;
+    h.n = v3(0.0f, 0.0f, 0.0f);
+    h.inside = false;
+    if (idx >= 0) h = finish_hit(tab, idx, o, d, t, true);
+    else t = 0.0f;
+    if (out.hit_id) out.hit_id[pixel] = idx;
+    if (out.t) out.t[pixel] = t;
+    if (out.normal) {
+        out.normal[3ull * pixel + 0] = h.n.x;
+        out.normal[3ull * pixel + 1] = h.n.y;
+        out.normal[3ull * pixel + 2] = h.n.z;
+    }
+    if (out.inside) out.inside[pixel] = h.inside ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256) k_divide(float *d, uint64_t n, float divisor)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        d[i] = d[i] / divisor;
+}
+
+static dim3 tile_grid(const RenderParams &p)
+{
+    uint32_t tiles = ((p.width + 7u) / 8u) * ((p.height + 7u) / 8u);
+    return dim3((tiles + 3u) / 4u);
+}
+
+hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, hipStream_t stream)
+{
+    dim3 grid = tile_grid(p), block(256);
+    size_t lds = src == kSrcLds ? scene_lds_bytes(p.n_prims, p.n_lights) : 0;
+    if (src == kSrcLds) {
+        if (stats) hipLaunchKernelGGL((k_megakernel<kSrcLds, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((k_megakernel<kSrcLds, false>), grid, block, lds, stream, p);
+    } else if (src == kSrcScalar) {
+        if (stats) hipLaunchKernelGGL((k_megakernel<kSrcScalar, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((k_megakernel<kSrcScalar, false>), grid, block, lds, stream, p);
+    } else {
+        if (stats) hipLaunchKernelGGL((k_megakernel<kSrcBvh, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((k_megakernel<kSrcBvh, false>), grid, block, lds, stream, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_primary(const RenderParams &p, const PrimaryParams &out, int src, hipStream_t stream)
+{
+    dim3 grid = tile_grid(p), block(256);
+    size_t lds = src == kSrcLds ? scene_lds_bytes(p.n_prims, p.n_lights) : 0;
+    if (src == kSrcLds) hipLaunchKernelGGL((k_primary<kSrcLds>), grid, block, lds, stream, p, out);
+    else if (src == kSrcScalar) hipLaunchKernelGGL((k_primary<kSrcScalar>), grid, block, lds, stream, p, out);
+    else hipLaunchKernelGGL((k_primary<kSrcBvh>), grid, block, lds, stream, p, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_divide(float *d, uint64_t n, float divisor, hipStream_t stream)
+{
+    uint64_t blocks = (n + 255u) / 256u;
+    if (blocks > 2048u) blocks = 2048u;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_divide, dim3((uint32_t)blocks), dim3(256), 0, stream, d, n, divisor);
+    return hipGetLastError();
+}
+
+}  // namespace rtx

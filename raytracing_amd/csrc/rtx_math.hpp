@@ -1,0 +1,101 @@
+// rtx_math.hpp -- device-side binary32 building blocks of the trace loop.
+//
+// Every expression is written in the order the reference evaluates it (rustc never
+// fuses a multiply-add; nalgebra's 3-vector kernels: dot = (x+y)+z, normalize = three
+// divisions by the length, quaternion rotation = ((t*w) + u x t) + v with t = (u x v)*2).
+// The translation unit must be compiled with -ffp-contract=off and with HIP's default
+// correctly rounded f32 division and square root, so results are bit-identical to an
+// IEEE host evaluation of the same expressions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rtx {
+
+#define RTX_DEV __device__ __forceinline__
+
+constexpr float kPi = 3.14159274101257324f;   // std::f32::consts::PI
+constexpr float kRayEps = 1e-4f;              // src/ray.rs:3
+constexpr float kInf = __builtin_huge_valf();
+
+struct V3 {
+    float x, y, z;
+};
+
+RTX_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+RTX_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+RTX_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+RTX_DEV V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+RTX_DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+RTX_DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+RTX_DEV V3 cmul(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+RTX_DEV V3 cdiv(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
+RTX_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+RTX_DEV float len2(V3 a) { return dot(a, a); }
+RTX_DEV float len(V3 a) { return __builtin_sqrtf(dot(a, a)); }
+RTX_DEV V3 normalize(V3 a) { return a / len(a); }
+RTX_DEV V3 cross(V3 a, V3 b)
+{
+    return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+RTX_DEV float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+
+// f32::min / f32::max of the reference's language: a NaN operand is ignored; on a tie
+// (including +0 / -0) the first operand is kept.
+RTX_DEV float rmin(float a, float b) { return (a != a) ? b : ((b < a) ? b : a); }
+RTX_DEV float rmax(float a, float b) { return (a != a) ? b : ((b > a) ? b : a); }
+RTX_DEV bool finite_f(float x) { return (x - x) == 0.0f; }
+
+// unit quaternion (x, y, z, w) applied to a vector; inverse = conjugate
+RTX_DEV V3 rotate(float4 q, V3 v)
+{
+    V3 u = v3(q.x, q.y, q.z);
+    V3 t = cross(u, v) * 2.0f;
+    V3 c = cross(u, t);
+    return (t * q.w + c) + v;
+}
+RTX_DEV V3 rotate_inv(float4 q, V3 v) { return rotate(make_float4(-q.x, -q.y, -q.z, q.w), v); }
+
+// sin and cos of x in [0, 2*pi]: Cody-Waite reduction by pi/2 in three steps, then the
+// Cephes single-precision polynomials on [-pi/4, pi/4].  The same operation sequence is
+// evaluated by the host-side checker, so both agree bit for bit.
+RTX_DEV void sincos_2pi(float x, float &s_out, float &c_out)
+{
+    int k = (int)(x * 0.636619747f + 0.5f);
+    float kf = (float)k;
+    float r = x - kf * 1.5703125f;
+    r = r - kf * 4.83751297e-4f;
+    r = r - kf * 7.54978942e-8f;
+    float r2 = r * r;
+    float s = ((-1.9515295891e-4f * r2 + 8.3321608736e-3f) * r2 - 1.6666654611e-1f) * r2 * r + r;
+    float c = ((2.443315711809948e-5f * r2 - 1.388731625493765e-3f) * r2 + 4.166664568298827e-2f) * r2 * r2
+              - 0.5f * r2 + 1.0f;
+    int q = k & 3;
+    float ss = (q & 1) ? c : s;
+    float cc = (q & 1) ? s : c;
+    s_out = (q & 2) ? -ss : ss;
+    c_out = (q == 1 || q == 2) ? -cc : cc;
+}
+
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11)
+RTX_DEV uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+// uniform draws as the reference's RNG crate forms them
+RTX_DEV float u24(uint32_t w) { return (float)(w >> 8) * 5.9604644775390625e-8f; }   // gen::<f32>()
+RTX_DEV float u23(uint32_t w) { return (float)(w >> 9) * 1.1920928955078125e-7f; }
+RTX_DEV float gen_range(uint32_t w, float lo, float hi) { return u23(w) * (hi - lo) + lo; }  // gen_range(lo..hi)
+
+}  // namespace rtx

@@ -1,0 +1,446 @@
+// rtx_trace.hpp -- per-lane pieces of the trace loop, shared by every kernel variant.
+//
+// What each piece follows in the reference:
+//   figure_t / figure_normal / figure_inside   src/objects/geometry.rs:56-147
+//   to_local / world_normal                     src/objects/geometry.rs:22-37
+//   closest_hit_scan                            src/trace.rs:102-121
+//   cosine_sample, light_surface_sample         src/random.rs:33-53, src/objects/sample.rs:13-85
+//   light_pdf, mis_pdf                          src/random.rs:83-128, 143-161
+//   reflect_dir, refract_dir, schlick           src/trace.rs:123-149
+//   scatter (one surface interaction)           src/trace.rs:21-100
+// Operation order inside every expression is the reference's; see rtx_math.hpp.
+#pragma once
+
+#include "rtx_device.h"
+#include "rtx_math.hpp"
+
+namespace rtx {
+
+// ------------------------------------------------------------------ counters
+template <bool ON>
+struct Counters {
+    uint32_t v[ON ? C_COUNT : 1];
+    RTX_DEV void clear()
+    {
+        if constexpr (ON) {
+#pragma unroll
+            for (int i = 0; i < C_COUNT; ++i) v[i] = 0;
+        }
+    }
+    template <int I>
+    RTX_DEV void add(bool cond = true)
+    {
+        if constexpr (ON) v[I] += cond ? 1u : 0u;
+    }
+};
+
+// ------------------------------------------------------------- object tables
+// View of the object table: pointers into LDS (staged copy) or global memory.
+struct Table {
+    const float4 *geom;
+    const float4 *mat;
+    const int32_t *lights;
+    uint32_t n_prims, n_lights;
+};
+
+struct Geom {
+    float4 rot;
+    V3 pos;
+    int kind;
+    V3 param;
+};
+RTX_DEV Geom load_geom(const float4 *g, uint32_t i)
+{
+    float4 a = g[3 * i + 0], b = g[3 * i + 1], c = g[3 * i + 2];
+    Geom r;
+    r.rot = a;
+    r.pos = v3(b.x, b.y, b.z);
+    r.kind = __float_as_int(b.w);
+    r.param = v3(c.x, c.y, c.z);
+    return r;
+}
+
+struct LocalRay {
+    V3 o, d;
+};
+// src/objects/geometry.rs:24-27: the direction is rotated only, so it keeps unit length
+RTX_DEV LocalRay to_local(const Geom &g, V3 o, V3 d)
+{
+    LocalRay r;
+    r.o = rotate_inv(g.rot, o - g.pos);
+    r.d = rotate_inv(g.rot, d);
+    return r;
+}
+
+// Distance along the local ray to the figure, or "no hit".
+RTX_DEV bool plane_t(V3 n, const LocalRay &r, float &t)
+{
+    t = -dot(r.o, n) / dot(r.d, n);
+    return !(t < 0.0f); // t = 0, -0 and NaN pass, as in the reference
+}
+RTX_DEV bool ellipsoid_t(V3 rad, const LocalRay &r, float &t)
+{
+    V3 u = cdiv(r.o, rad);
+    V3 v = cdiv(r.d, rad);
+    float a = len2(v);
+    float b = dot(u, v);
+    float c = len2(u) - 1.0f;
+    float det = b * b - a * c;
+    if (det < 0.0f) return false;
+    float sq = __builtin_sqrtf(det);
+    float t1 = (-b + sq) / a;
+    float t2 = (-b - sq) / a;
+    float lo = rmin(t1, t2), hi = rmax(t1, t2);
+    if (lo > 0.0f) { t = lo; return true; }
+    if (hi > 0.0f) { t = hi; return true; }
+    return false;
+}
+RTX_DEV bool box_t(V3 s, const LocalRay &r, float &t)
+{
+    float ax1 = (s.x - r.o.x) / r.d.x, ax2 = (-s.x - r.o.x) / r.d.x;
+    float ay1 = (s.y - r.o.y) / r.d.y, ay2 = (-s.y - r.o.y) / r.d.y;
+    float az1 = (s.z - r.o.z) / r.d.z, az2 = (-s.z - r.o.z) / r.d.z;
+    float t1 = rmax(rmax(rmin(ax1, ax2), rmin(ay1, ay2)), rmin(az1, az2));
+    float t2 = rmin(rmin(rmax(ax1, ax2), rmax(ay1, ay2)), rmax(az1, az2));
+    if (t1 > t2) return false;
+    if (t1 >= 0.0f) { t = t1; return true; }
+    if (t2 >= 0.0f) { t = t2; return true; }
+    return false;
+}
+RTX_DEV bool figure_t(int kind, V3 param, const LocalRay &r, float &t)
+{
+    if (kind == kPlane) return plane_t(param, r, t);
+    if (kind == kEllipsoid) return ellipsoid_t(param, r, t);
+    return box_t(param, r, t);
+}
+// Local (unnormalised) normal at distance t.
+RTX_DEV V3 figure_normal(int kind, V3 param, const LocalRay &r, float t)
+{
+    if (kind == kPlane) return param;
+    if (kind == kEllipsoid) {
+        V3 u = cdiv(r.o, param);
+        V3 v = cdiv(r.d, param);
+        return cdiv(u + v * t, param);
+    }
+    V3 n = cdiv(r.o + r.d * t, param);
+    // keep the first component of largest magnitude, zero the other two
+    float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+    int im = 0;
+    float vm = ax;
+    if (ay > vm) { vm = ay; im = 1; }
+    if (az > vm) { vm = az; im = 2; }
+    return v3(im == 0 ? n.x : 0.0f, im == 1 ? n.y : 0.0f, im == 2 ? n.z : 0.0f);
+}
+RTX_DEV bool figure_inside(int kind, V3 param, V3 o)
+{
+    if (kind == kPlane) return dot(param, o) < 0.0f;
+    if (kind == kEllipsoid) return len2(cdiv(o, param)) < 1.0f;
+    V3 q = cdiv(o, param);
+    return rmax(rmax(fabsf(q.x), fabsf(q.y)), fabsf(q.z)) < 1.0f;
+}
+// src/objects/geometry.rs:30-33
+RTX_DEV V3 world_normal(const Geom &g, V3 n_local, V3 d_world)
+{
+    V3 n = normalize(rotate(g.rot, n_local));
+    if (dot(n, d_world) > 0.0f) n = -n;
+    return n;
+}
+
+// Closest hit over the whole table, linear scan in object order.  The first object
+// reaching the minimum keeps it (strict <).  `i` is wave-uniform, so the table reads
+// are broadcasts (LDS) or scalar loads (global).
+template <bool UNIFORM_KIND>
+RTX_DEV int closest_hit_scan(const Table &tab, V3 o, V3 d, float &best_t)
+{
+    float ray_length = len(d);
+    int best = -1;
+    best_t = kInf;
+    for (uint32_t i = 0; i < tab.n_prims; ++i) {
+        Geom g = load_geom(tab.geom, i);
+        LocalRay lr = to_local(g, o, d);
+        int kind = UNIFORM_KIND ? __builtin_amdgcn_readfirstlane(g.kind) : g.kind;
+        float t;
+        bool hit = figure_t(kind, g.param, lr, t);
+        // src/trace.rs:113-119 with max_dist = +inf drops NaN and +inf distances
+        hit = hit && (t * ray_length < kInf);
+        if (hit && (best < 0 || t < best_t)) {
+            best_t = t;
+            best = (int)i;
+        }
+    }
+    return best;
+}
+
+struct Hit {
+    V3 n;        // unit, facing against the ray
+    bool inside;
+};
+// Normal and inside flag of object `idx` for the ray that hit it at distance t.
+RTX_DEV Hit finish_hit(const Table &tab, int idx, V3 o, V3 d, float t, bool want_inside)
+{
+    Geom g = load_geom(tab.geom, (uint32_t)idx);
+    LocalRay lr = to_local(g, o, d);
+    Hit h;
+    h.n = world_normal(g, figure_normal(g.kind, g.param, lr, t), d);
+    h.inside = want_inside ? figure_inside(g.kind, g.param, lr.o) : false;
+    return h;
+}
+
+// -------------------------------------------------------------------- lights
+// Full intersection of one light with a world ray: distance and world normal.
+RTX_DEV bool light_intersect(const Geom &g, V3 o, V3 d, float &t, V3 &n)
+{
+    LocalRay lr = to_local(g, o, d);
+    if (!figure_t(g.kind, g.param, lr, t)) return false;
+    n = world_normal(g, figure_normal(g.kind, g.param, lr, t), d);
+    return true;
+}
+// src/objects/sample.rs:19-22 over :53-57 (box) and :66-74 (ellipsoid)
+RTX_DEV float light_area_pdf(const Geom &g, V3 point)
+{
+    V3 q = rotate_inv(g.rot, point - g.pos);
+    if (g.kind == kBox) {
+        float a = g.param.x, b = g.param.y, c = g.param.z;
+        float area = 8.0f * ((a * b + b * c) + a * c);
+        return 1.0f / area;
+    }
+    V3 n = cdiv(q, g.param);
+    n = cmul(n, n);
+    V3 r = cmul(g.param, g.param);
+    float denom = (n.x * r.y * r.z + r.x * n.y * r.z) + r.x * r.y * n.z;
+    return 1.0f / (4.0f * kPi * __builtin_sqrtf(denom));
+}
+// src/random.rs:112-128
+RTX_DEV float intersection_pdf(const Geom &g, V3 o, V3 d, float t, V3 n, V3 initial_point)
+{
+    V3 obj_point = o + d * t;
+    float dist = len2(initial_point - obj_point);
+    float cosv = fabsf(dot(d, n));
+    float pdf = light_area_pdf(g, obj_point) * dist / cosv;
+    return finite_f(pdf) ? pdf : 0.0f;
+}
+// src/random.rs:83-109: every light is intersected by the ray from p along d, and again
+// from just behind the first hit, to collect the far side of the surface.
+template <bool STATS>
+RTX_DEV float light_pdf(const Table &tab, V3 p, V3 dir, Counters<STATS> &cnt)
+{
+    if (tab.n_lights == 0) return 0.0f;
+    V3 d = normalize(dir);
+    float pdf = 0.0f;
+    for (uint32_t li = 0; li < tab.n_lights; ++li) {
+        Geom g = load_geom(tab.geom, (uint32_t)tab.lights[li]);
+        cnt.template add<C_LTEST_ELLIPSOID>(g.kind == kEllipsoid);
+        cnt.template add<C_LTEST_BOX>(g.kind == kBox);
+        float t1, t2;
+        V3 n1, n2;
+        if (!light_intersect(g, p, d, t1, n1)) {
+            cnt.template add<C_LPDF_0>();
+            continue;
+        }
+        pdf += intersection_pdf(g, p, d, t1, n1, p);
+        // Ray::new_shifted normalises the (already unit) direction once more
+        V3 d2 = normalize(d);
+        V3 o2 = (p + d * t1) + d2 * kRayEps;
+        cnt.template add<C_LTEST_ELLIPSOID>(g.kind == kEllipsoid);
+        cnt.template add<C_LTEST_BOX>(g.kind == kBox);
+        if (!light_intersect(g, o2, d2, t2, n2)) {
+            cnt.template add<C_LPDF_1>();
+            continue;
+        }
+        pdf += intersection_pdf(g, o2, d2, t2, n2, p);
+        cnt.template add<C_LPDF_2>();
+    }
+    return pdf / (float)tab.n_lights;
+}
+// src/random.rs:143-161
+template <bool STATS>
+RTX_DEV float mis_pdf(const Table &tab, V3 p, V3 n, V3 d, Counters<STATS> &cnt)
+{
+    float a = tab.n_lights == 0 ? 1.0f : 0.5f;
+    float cos_pdf = rmax(dot(n, d), 0.0f) / kPi;
+    return cos_pdf * a + light_pdf<STATS>(tab, p, d, cnt) * (1.0f - a);
+}
+
+// ------------------------------------------------------------------ sampling
+// src/random.rs:33-53
+RTX_DEV V3 cosine_sample(V3 n, uint32_t w_theta, uint32_t w_r)
+{
+    float theta = gen_range(w_theta, 0.0f, 2.0f * kPi);
+    float r = __builtin_sqrtf(gen_range(w_r, 0.0f, 1.0f));
+    float st, ct;
+    sincos_2pi(theta, st, ct);
+    float x = r * ct;
+    float y = r * st;
+    float z = __builtin_sqrtf(1.0f - x * x - y * y);
+
+    float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+    float m = rmin(rmin(ax, ay), az);
+    V3 xi = v3(ax > m ? 0.0f : 1.0f, ay > m ? 0.0f : 1.0f, az > m ? 0.0f : 1.0f);
+    xi = normalize(xi - n * dot(xi, n));
+    V3 yi = normalize(cross(xi, n));
+    return v3((xi.x * x + yi.x * y) + n.x * z,
+              (xi.y * x + yi.y * y) + n.y * z,
+              (xi.z * x + yi.z * y) + n.z * z);
+}
+// src/objects/sample.rs:13-17 over :25-51 (box) and :60-64, :78-85 (ellipsoid).
+// Word 0 of the draw block: bit 30 = the face sign; words 1..3: the floats.
+RTX_DEV V3 light_surface_sample(const Geom &g, uint4 w)
+{
+    V3 point;
+    if (g.kind == kBox) {
+        float a = g.param.x, b = g.param.y, c = g.param.z;
+        float area = (a * b + b * c) + a * c;
+        float x = gen_range(w.y, 0.0f, area);
+        // the face-picking chain never yields the x faces: its third branch repeats z
+        bool y_face = !(x < a * b) && (x < a * b + a * c);
+        float sgn = ((w.x >> 30) & 1u) == 0u ? -1.0f : 1.0f;
+        // the picked axis carries +-size, the two others are redrawn in axis order from
+        // words 2 and 3 (a zero half-size on the picked axis is rejected at scene set-up)
+        float px = gen_range(w.z, -a, a);
+        float py, pz;
+        if (y_face) {
+            py = sgn * b;
+            pz = gen_range(w.w, -c, c);
+        } else {
+            py = gen_range(w.w, -b, b);
+            pz = sgn * c;
+        }
+        point = v3(px, py, pz);
+    } else {
+        float phi = u24(w.y) * kPi;
+        float z = u24(w.z) * 2.0f - 1.0f;
+        float sp, cp;
+        sincos_2pi(phi, sp, cp);
+        float x = __builtin_sqrtf(1.0f - z * z) * cp;
+        float y = __builtin_sqrtf(1.0f - z * z) * sp;
+        point = cmul(v3(x, y, z), g.param);
+    }
+    return rotate(g.rot, point) + g.pos;
+}
+
+// --------------------------------------------------------- specular helpers
+RTX_DEV V3 reflect_dir(V3 d, V3 n) { return d - (n * 2.0f) * dot(d, n); }
+RTX_DEV bool refract_dir(V3 d, V3 n, float eta, V3 &out)
+{
+    float cos1 = -dot(n, d);
+    float sin2 = eta * __builtin_sqrtf(1.0f - cos1 * cos1);
+    if (fabsf(sin2) > 1.0f) return false;
+    float cos2 = __builtin_sqrtf(1.0f - sin2 * sin2);
+    out = d * eta + n * (eta * cos1 - cos2);
+    return true;
+}
+RTX_DEV float schlick(float eta, float cosv)
+{
+    float r0 = (eta - 1.0f) / (eta + 1.0f);
+    r0 = r0 * r0;
+    float x = 1.0f - cosv;
+    float x2 = x * x;
+    float x4 = x2 * x2;
+    return r0 + (1.0f - r0) * (x * x4);
+}
+
+// ------------------------------------------------------------ path stepping
+struct Path {
+    V3 o, d;      // current ray
+    V3 T;         // throughput
+    V3 L;         // radiance gathered so far by this sample
+    uint32_t depth;
+};
+
+RTX_DEV uint4 draw_block(const RenderParams &P, uint32_t pixel, uint32_t sample, uint32_t slot)
+{
+    if (P.rng_const) return make_uint4(P.const_words[0], P.const_words[1], P.const_words[2], P.const_words[3]);
+    return philox4x32_10(pixel, sample, slot, 0u, P.seed_lo, P.seed_hi);
+}
+
+// src/main.rs:17-21 + src/camera.rs:15-22: pixel (i, j), j counted from the bottom row
+RTX_DEV void camera_ray(const RenderParams &P, uint32_t i, uint32_t j, float du, float dv, V3 &o, V3 &d)
+{
+    float u = ((float)i + du) / (float)P.width * 2.0f - 1.0f;
+    float v = ((float)j + dv) / (float)P.height * 2.0f - 1.0f;
+    float dx = u * P.tg_fov_x, dy = v * P.tg_fov_y, dz = 1.0f;
+    const float *m = P.cam_axis;
+    V3 dir = v3((m[0] * dx + m[3] * dy) + m[6] * dz,
+                (m[1] * dx + m[4] * dy) + m[7] * dz,
+                (m[2] * dx + m[5] * dy) + m[8] * dz);
+    o = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
+    d = normalize(dir);
+}
+
+// One surface interaction at object `idx`, distance t along the path's ray: adds the
+// emission, then scatters.  Returns true when the path ends here.  The scatter at the
+// last allowed depth is skipped: its child ray would be cut before intersecting
+// (src/trace.rs:12-14) and contribute zero.
+template <bool STATS>
+RTX_DEV bool scatter(const RenderParams &P, const Table &tab, Path &p, int idx, float t,
+                     uint32_t pixel, uint32_t sample, Counters<STATS> &cnt)
+{
+    float4 m0 = tab.mat[2 * idx + 0], m1 = tab.mat[2 * idx + 1];
+    V3 color = v3(m0.x, m0.y, m0.z), emission = v3(m1.x, m1.y, m1.z);
+    int material = __float_as_int(m0.w);
+    p.L = p.L + cmul(p.T, emission);
+    if (p.depth + 1 >= P.ray_depth) return true;
+
+    Hit h = finish_hit(tab, idx, p.o, p.d, t, material == kDielectric);
+    V3 point = p.o + p.d * t;
+    V3 n = h.n;
+
+    if (material == kDiffuse) {
+        V3 color_obj = color / kPi;
+        uint4 w = draw_block(P, pixel, sample, p.depth + 1);
+        V3 new_dir;
+        bool pick_cosine = tab.n_lights == 0 || (w.x >> 31) == 0u;
+        if (pick_cosine) {
+            cnt.template add<C_COSINE>();
+            new_dir = cosine_sample(n, w.y, w.z);
+        } else {
+            uint32_t li = __umulhi(w.x << 2, tab.n_lights);
+            Geom lg = load_geom(tab.geom, (uint32_t)tab.lights[li]);
+            cnt.template add<C_LSAMPLE_ELLIPSOID>(lg.kind == kEllipsoid);
+            cnt.template add<C_LSAMPLE_BOX>(lg.kind == kBox);
+            new_dir = normalize(light_surface_sample(lg, w) - point);
+        }
+        if (dot(new_dir, n) < 0.0f) return true;
+        cnt.template add<C_PDF_EVALS>();
+        float pdf = mis_pdf<STATS>(tab, point, n, new_dir, cnt);
+        if (!finite_f(pdf) || pdf < 1e-6f) return true;
+        V3 nd = normalize(new_dir);
+        float cosv = dot(n, nd);
+        p.T = (cmul(p.T, color_obj) * cosv) / pdf;
+        p.o = point + nd * kRayEps;
+        p.d = nd;
+        cnt.template add<C_DIFFUSE>();
+    } else if (material == kMetallic) {
+        V3 nd = normalize(reflect_dir(p.d, n));
+        p.T = cmul(p.T, color);
+        p.o = point + nd * kRayEps;
+        p.d = nd;
+        cnt.template add<C_METALLIC>();
+    } else {
+        float ior = m1.w;
+        float eta = h.inside ? ior : 1.0f / ior;
+        V3 rdir = reflect_dir(p.d, n);
+        V3 fdir;
+        bool can_refract = refract_dir(p.d, n, eta, fdir);
+        float coeff = schlick(eta, -dot(p.d, n));
+        bool take_refracted = false;
+        if (can_refract) {
+            uint4 w = draw_block(P, pixel, sample, p.depth + 1);
+            take_refracted = u24(w.y) < 1.0f - coeff;
+        }
+        V3 nd;
+        if (take_refracted) {
+            if (!h.inside) p.T = cmul(p.T, color);
+            nd = normalize(fdir);
+        } else {
+            nd = normalize(rdir);
+        }
+        p.o = point + nd * kRayEps;
+        p.d = nd;
+        cnt.template add<C_DIELECTRIC>();
+    }
+    p.depth += 1;
+    return false;
+}
+
+}  // namespace rtx
