@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-pixel trace loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one complete render of the workload: every pixel x every sample through the
+HIP kernels, the per-GPU radiance sums combined (RCCL all-reduce when N > 1) and
+divided by the sample count.  The scene and the output buffer are resident in HBM
+before the timed region starts.
+
+Workloads (BASELINE.json configs):
+  c2  reference scene at 1920x1080, 256 spp, depth 6, seed 1      (default for N = 1)
+  c4  reference scene at 3840x2160, 1024 spp, samples split over the N GPUs
+      (default for N > 1; fixed total work, so scaling = "strong")
+  c3  synthetic 10k-object scene, 1080p, 64 spp, BVH
+  c5  dielectric / metallic scene, depth 16, 1080p, 256 spp
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def build_workload(name, spp_override=None, size_override=None):
+    from raytracing_amd import reference_scene, dielectric_scene, synthetic_scene
+    if name == "c2":
+        sc, desc = reference_scene(1920, 1080, 256, 6), "reference scene (8 objects, 1 light), 1920x1080, 256 spp, depth 6"
+    elif name == "c4":
+        sc, desc = reference_scene(3840, 2160, 1024, 6), "reference scene, 3840x2160, 1024 spp, depth 6, spp split over GPUs"
+    elif name == "c3":
+        sc, desc = synthetic_scene(10000, 12345, 1920, 1080, 64, 6), "synthetic 10k objects (8 lights), 1920x1080, 64 spp, depth 6, BVH"
+    elif name == "c5":
+        sc, desc = dielectric_scene(1920, 1080, 256, 16), "dielectric/metallic scene (33 objects), 1920x1080, 256 spp, depth 16"
+    elif name == "c1":
+        sc, desc = reference_scene(512, 512, 10, 6), "reference scene at its native 512x512, 10 spp, depth 6"
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    if size_override:
+        sc = sc.replace(width=size_override[0], height=size_override[1])
+        desc += f" [size overridden to {size_override[0]}x{size_override[1]}]"
+    if spp_override:
+        sc = sc.replace(n_samples=spp_override)
+        desc += f" [spp overridden to {spp_override}]"
+    return sc, desc
+
+
+def cpu_baseline(scene, seconds_target=15.0):
+    """The oracle (C restatement of the reference, 1 thread, reference evaluation order)
+    timed on this host on a bounded sample of the same workload."""
+    from oracle import pyoracle
+    small = scene.replace(width=240, height=135, n_samples=4)
+    t0 = time.perf_counter()
+    pyoracle.render(small, seed=1, order=pyoracle.ORDER_REFERENCE)
+    dt = time.perf_counter() - t0
+    rate = small.width * small.height * small.n_samples / dt
+    spp = max(4, min(256, int(seconds_target * rate / (480 * 270))))
+    sample = scene.replace(width=480, height=270, n_samples=spp)
+    t0 = time.perf_counter()
+    pyoracle.render(sample, seed=1, order=pyoracle.ORDER_REFERENCE)
+    dt = time.perf_counter() - t0
+    n = sample.width * sample.height * sample.n_samples
+    return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"same scene at 480x270, {spp} spp ({n} samples, {dt:.1f} s), "
+                      "C restatement of the reference (not the Rust binary), gcc -O2 -ffp-contract=off, 1 thread",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--mode", default="megakernel", choices=["megakernel", "wavefront"])
+    ap.add_argument("--accel", default="auto", choices=["auto", "lds", "scalar", "bvh"])
+    ap.add_argument("--spp", type=int, default=None)
+    ap.add_argument("--size", type=int, nargs=2, default=None)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stats", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import _abi
+    from raytracing_amd.renderer import Renderer
+    from raytracing_amd.flops import (algorithmic_flops, PEAK_FP32_VECTOR_TFLOPS, PEAK_FP32_NONPACKED_TFLOPS)
+    from raytracing_amd.parallel import sample_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    name = args.workload or ("c2" if world == 1 else "c4")
+    scene, desc = build_workload(name, args.spp, args.size)
+    mode = {"megakernel": _abi.MODE_MEGAKERNEL, "wavefront": _abi.MODE_WAVEFRONT}[args.mode]
+    accel = {"auto": _abi.ACCEL_AUTO, "lds": _abi.ACCEL_BRUTE_LDS, "scalar": _abi.ACCEL_BRUTE_SCALAR,
+             "bvh": _abi.ACCEL_BVH}[args.accel]
+    first, count = sample_range(scene.n_samples, rank, world)
+    n_floats = scene.width * scene.height * 3
+    buf = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    r = Renderer(seed=args.seed, mode=mode, accel=accel, device=local_rank)
+    r.set_scene(scene)
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        r.render_samples(first, count, buf.data_ptr(), stream)
+        if ev:
+            ev[1].record()
+        if world > 1:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        r.divide(buf.data_ptr(), n_floats, float(scene.n_samples), stream)
+
+    for _ in range(args.warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+    checksum = float(buf.double().sum().item())
+
+    # event counters of this rank's share: an untimed launch of the counting kernels on
+    # the same inputs (paths are deterministic, so the events are those of a timed step)
+    stats = None
+    if not args.no_stats:
+        rs = Renderer(seed=args.seed, mode=mode, accel=accel, device=local_rank, collect_stats=True)
+        rs.set_scene(scene)
+        rs.render_samples(first, count, buf.data_ptr(), stream)
+        torch.cuda.synchronize()
+        stats = rs.stats()
+        rs.close()
+    total_samples = scene.width * scene.height * scene.n_samples
+    rays_total = None
+    roofline = None
+    if stats is not None:
+        flops_rank = algorithmic_flops(stats)
+        achieved = flops_rank / (kernel_ms * 1e-3) / 1e12
+        roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,
+                    "frac_of_nonpacked_fma_peak": achieved / PEAK_FP32_NONPACKED_TFLOPS,
+                    "kernel": "k_megakernel" if mode == _abi.MODE_MEGAKERNEL else "wavefront stages",
+                    "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_rank,
+                    "flops_per_sample": flops_rank / max(1, stats["samples"]),
+                    "rays_per_sample": stats["rays"] / max(1, stats["samples"])}
+        rays = torch.tensor([stats["rays"]], dtype=torch.float64, device="cuda")
+        if world > 1:
+            dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        rays_total = float(rays.item())
+
+    if rank == 0:
+        value = total_samples * args.steps / elapsed / 1e6
+        out = {
+            "metric": "Msamples/sec (whole node)", "value": value, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if name == "c4" else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{name}: {desc}", "mode": args.mode, "accel": args.accel, "seed": args.seed,
+                       "samples_per_step": total_samples,
+                       "parallelism": f"spp-split x{world} + all-reduce" if world > 1 else "single GPU"},
+            "mrays_per_s": (rays_total * args.steps / elapsed / 1e6) if rays_total else None,
+            "checksum": checksum,
+        }
+        if roofline:
+            out["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline(scene)
+            out["cpu_baseline"] = cb
+            out["speedup_vs_cpu_1thread"] = value / cb["value"]
+        print(json.dumps(out), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
