@@ -1,0 +1,344 @@
+"""Known-answer tests that pin the CPU oracle (PARITY UNPINNED by the reference itself:
+it ships no tests or golden outputs).  Vectors are derived analytically from the
+reference's formulas, file:line cited per test (paths relative to the reference root).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from raytracing_amd import _abi, reference_scene, dielectric_scene, Prim, normalize_quaternion
+
+PLANE, ELL, BOX = _abi.PLANE, _abi.ELLIPSOID, _abi.BOX
+
+
+# ------------------------------------------------------------------ RNG, sin/cos
+def test_philox4x32_10_published_vectors(oracle):
+    """Random123 kat_vectors for philox4x32-10."""
+    assert oracle.philox((0, 0, 0, 0), (0, 0)) == (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)
+    assert oracle.philox((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2) == (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)
+    assert oracle.philox((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0)) == \
+        (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1)
+
+
+def test_sincos_accuracy(oracle):
+    """The shared sin/cos polynomial on [0, 2*pi] (the only range src/random.rs:34 and
+    src/objects/sample.rs:79 feed it): absolute error <= 2^-23 everywhere and <= 2 ulp
+    away from the zeros."""
+    xs = np.concatenate([np.linspace(0, 2 * math.pi, 20001), [0.0, math.pi / 2, math.pi, 6.2831855]]).astype(np.float32)
+    worst_abs = worst_ulp = 0.0
+    for x in xs:
+        s, c = oracle.sincos(float(x))
+        for got, want in ((s, math.sin(float(x))), (c, math.cos(float(x)))):
+            worst_abs = max(worst_abs, abs(got - want))
+            if abs(want) > 1e-3:
+                worst_ulp = max(worst_ulp, abs(got - want) / float(np.spacing(np.float32(abs(want)))))
+    assert worst_abs <= 2.0 ** -23, worst_abs
+    assert worst_ulp <= 2.0, worst_ulp
+
+
+# ------------------------------------------------------- analytic hits in the scene
+def test_camera_tangents(oracle):
+    sc = reference_scene()
+    assert sc.tangents() == (0.5, 0.5)  # tan(0.927295218 / 2), assets/scene.txt:11, src/parser.rs:53-55
+    assert reference_scene(1920, 1080).tangents() == (0.5, 0.28125)
+
+
+def test_ray_hits_light_bottom_face(oracle):
+    """(u,v) = (0, 0.65333): dir ~ (0,4.9,-15) hits the light's bottom face at (0,4.9,0):
+    t = sqrt(4.9^2+15^2) = 15.7800, n = (0,-1,0); the ceiling (id 2, y=5) is farther."""
+    sc = reference_scene()
+    o, d = oracle.camera_ray(sc, 0.0, 0.65333)
+    idx, t, n, inside = oracle.closest_hit(sc, o, d)
+    assert idx == 5 and not inside
+    assert t == pytest.approx(math.hypot(4.9, 15.0), rel=2e-5)
+    assert n == (0.0, -1.0, 0.0)
+
+
+def test_ray_through_sphere_centre(oracle):
+    sc = reference_scene()
+    o, d = oracle.camera_ray(sc, 4 / 13, -6 / 13)
+    idx, t, n, inside = oracle.closest_hit(sc, o, d)
+    assert idx == 7 and not inside
+    assert t == pytest.approx(math.sqrt(182) - 2, rel=1e-6)
+    # the normal points back along the ray
+    assert np.allclose(n, -np.asarray(d), atol=1e-6)
+
+
+def test_ray_hits_floor(oracle):
+    sc = reference_scene()
+    o, d = oracle.camera_ray(sc, 0.0, -0.9)
+    idx, t, n, inside = oracle.closest_hit(sc, o, d)
+    assert idx == 0 and n == (0.0, 1.0, 0.0)
+    assert t == pytest.approx((5 / 0.45) * math.sqrt(1 + 0.45 ** 2), rel=1e-6)
+
+
+def test_image_centre_grazes_rotated_box(oracle):
+    """Robustness probe: the centre ray grazes the +x corner of the rotated box."""
+    sc = reference_scene()
+    o, d = oracle.camera_ray(sc, 0.0, 0.0)
+    idx, t, n, inside = oracle.closest_hit(sc, o, d)
+    assert idx in (6, 1)
+    if idx == 6:
+        assert t == pytest.approx(15.88, abs=0.01)
+
+
+def test_lights_are_emissive_boxes_and_ellipsoids_only(oracle):
+    """src/parser.rs:69-89: planes are never lights."""
+    sc = reference_scene()
+    assert oracle.lights(sc) == [5] == sc.light_indices()
+    sc.prims[0] = Prim(PLANE, (0, 1, 0), position=(0, -5, 0), color=(1, 1, 1), emission=(1, 1, 1))
+    sc.prims[7] = Prim(ELL, (2, 2, 2), position=(2, -3, 2), emission=(0, 0, 1e-30))  # squares underflow to 0
+    assert oracle.lights(sc) == [5]
+    sc.prims[7] = Prim(ELL, (2, 2, 2), position=(2, -3, 2), emission=(0, 0, 1e-10))
+    assert oracle.lights(sc) == [5, 7]
+
+
+# ----------------------------------------------------- per-primitive unit cases
+def test_plane_cases(oracle):
+    """src/objects/geometry.rs:56-71: t = -(o.n)/(d.n); t < 0 rejected, t = 0 accepted."""
+    n = (0, 1, 0)
+    assert oracle.figure_intersect(PLANE, n, (0, 2, 0), (0, -1, 0)) == (2.0, (0.0, 1.0, 0.0), False)
+    assert oracle.figure_intersect(PLANE, n, (0, -2, 0), (0, 1, 0)) == (2.0, (0.0, 1.0, 0.0), True)
+    assert oracle.figure_intersect(PLANE, n, (0, 2, 0), (0, 1, 0)) is None          # behind
+    assert oracle.figure_intersect(PLANE, n, (0, 0, 0), (0, -1, 0))[0] == 0.0       # t = 0 passes
+    # parallel ray: t = -inf is rejected here; t = +inf / NaN pass and are dropped by the
+    # range filter of src/trace.rs:113-119
+    assert oracle.figure_intersect(PLANE, n, (0, 2, 0), (1, 0, 0)) is None
+    t = oracle.figure_intersect(PLANE, n, (0, -2, 0), (1, 0, 0))[0]
+    assert t == math.inf
+    assert math.isnan(oracle.figure_intersect(PLANE, n, (0, 0, 0), (1, 0, 0))[0])
+    # an unnormalised normal is returned as given (src/objects/geometry.rs:66)
+    assert oracle.figure_intersect(PLANE, (0, 3, 0), (0, 2, 0), (0, -1, 0))[1] == (0.0, 3.0, 0.0)
+
+
+def test_parallel_plane_ray_is_dropped_by_closest_hit(oracle):
+    sc = reference_scene().replace(prims=[Prim(PLANE, (0, 1, 0), position=(0, 1, 0))])
+    assert oracle.closest_hit(sc, (0, 0, 0), (1, 0, 0))[0] == -1     # t = +inf
+    assert oracle.closest_hit(sc, (0, 1, 0), (1, 0, 0))[0] == -1     # t = NaN
+    assert oracle.closest_hit(sc, (0, 0, 0), (0, 1, 0))[0] == 0
+
+
+def test_ellipsoid_cases(oracle):
+    """src/objects/geometry.rs:73-107."""
+    r = (2, 1, 1)
+    t, n, inside = oracle.figure_intersect(ELL, r, (-5, 0, 0), (1, 0, 0))
+    assert (t, inside) == (3.0, False) and n == (-0.5, 0.0, 0.0)     # n = (u + t v)/r, unnormalised
+    t, n, inside = oracle.figure_intersect(ELL, r, (0, 0, 0), (1, 0, 0))
+    assert (t, inside) == (2.0, True) and n == (0.5, 0.0, 0.0)
+    assert oracle.figure_intersect(ELL, r, (5, 0, 0), (1, 0, 0)) is None             # both roots negative
+    assert oracle.figure_intersect(ELL, r, (-5, 2, 0), (1, 0, 0)) is None            # det < 0
+    # tangent ray: det = 0, one root, strictly positive -> hit
+    t, n, inside = oracle.figure_intersect(ELL, (1, 1, 1), (-3, 1, 0), (1, 0, 0))
+    assert t == 3.0 and not inside
+    # on the surface looking out: roots 0 and -2; t must be > 0 (strict) -> miss
+    assert oracle.figure_intersect(ELL, (1, 1, 1), (1, 0, 0), (1, 0, 0)) is None
+
+
+def test_box_cases(oracle):
+    """src/objects/geometry.rs:109-147."""
+    s = (1, 2, 3)
+    t, n, inside = oracle.figure_intersect(BOX, s, (-4, 0, 0), (1, 0, 0))           # d.y = d.z = 0: +-inf slabs
+    assert (t, inside) == (3.0, False) and n == (-1.0, 0.0, 0.0)
+    t, n, inside = oracle.figure_intersect(BOX, s, (0, 0, 0), (0, 0, 1))             # from inside -> far root
+    assert (t, inside) == (3.0, True) and n == (0.0, 0.0, 1.0)
+    assert oracle.figure_intersect(BOX, s, (-4, 5, 0), (1, 0, 0)) is None            # parallel, outside the y slab
+    assert oracle.figure_intersect(BOX, s, (4, 0, 0), (1, 0, 0)) is None             # behind
+    # on a face looking in: t1 = 0 is accepted (>=)
+    assert oracle.figure_intersect(BOX, s, (-1, 0, 0), (1, 0, 0))[0] == 0.0
+    # exact corner hit: |n| ties -> the FIRST maximal component is kept (argmax is strict)
+    d = np.array([1, 1, 1], dtype=np.float32) / np.sqrt(np.float32(3))
+    t, n, inside = oracle.figure_intersect(BOX, (1, 1, 1), (-2, -2, -2), tuple(d))
+    assert n[1] == 0.0 and n[2] == 0.0 and n[0] == pytest.approx(-1.0, abs=1e-6)
+
+
+def test_positioned_figure_flips_normal_towards_ray(oracle):
+    """src/objects/geometry.rs:22-37: rotate, normalise, flip if n.d > 0."""
+    q = normalize_quaternion(0, 0.3826834, 0, 0.9238795)   # 45 degrees about y
+    sc = reference_scene().replace(prims=[Prim(BOX, (1, 1, 1), position=(0, 0, -5), rotation=q)])
+    idx, t, n, inside = oracle.closest_hit(sc, (0, 0, 0), (0, 0, -1))
+    assert idx == 0 and t == pytest.approx(5 - math.sqrt(2), rel=1e-5)
+    assert abs(n[1]) < 1e-6 and abs(abs(n[0]) - math.sqrt(0.5)) < 1e-5 and n[2] == pytest.approx(math.sqrt(0.5), rel=1e-5)
+    # from inside the box the normal points back at the origin of the ray
+    idx, t, n, inside = oracle.closest_hit(sc, (0, 0, -5), (0, 0, -1))
+    assert inside and n[2] > 0
+
+
+def test_first_object_wins_ties(oracle):
+    """src/trace.rs:120: min_by keeps the first minimum."""
+    a = Prim(PLANE, (0, 0, 1), position=(0, 0, -3), color=(1, 0, 0))
+    b = Prim(PLANE, (0, 0, 1), position=(0, 0, -3), color=(0, 1, 0))
+    sc = reference_scene().replace(prims=[a, b])
+    assert oracle.closest_hit(sc, (0, 0, 0), (0, 0, -1))[0] == 0
+    sc = reference_scene().replace(prims=[Prim(PLANE, (0, 0, 1), position=(0, 0, -4)), a, b])
+    assert oracle.closest_hit(sc, (0, 0, 0), (0, 0, -1))[0] == 1
+
+
+# ------------------------------------------------------------ specular materials
+def test_reflection(oracle):
+    """src/trace.rs:123-126 with Ray::new_shifted (src/ray.rs:18-24)."""
+    s = math.sqrt(0.5)
+    o, d = oracle.reflect((s, -s, 0), (1, 2, 3), (0, 1, 0))
+    assert d == pytest.approx((s, s, 0), abs=1e-6)
+    assert o == pytest.approx((1 + 1e-4 * s, 2 + 1e-4 * s, 3), abs=1e-6)
+
+
+def test_refraction_and_total_internal_reflection(oracle):
+    """src/trace.rs:128-142: leaving glass (eta = 1.5) TIR starts at asin(1/1.5) = 41.81 deg."""
+    for deg, expect in [(0, True), (30, True), (41.0, True), (42.5, False), (60, False)]:
+        a = math.radians(deg)
+        res = oracle.refract((math.sin(a), -math.cos(a), 0), (0, 0, 0), (0, 1, 0), 1.5)
+        assert (res is not None) == expect, deg
+        if res:
+            o, d = res
+            assert math.hypot(d[0], d[2]) == pytest.approx(1.5 * math.sin(a), abs=1e-5)   # Snell
+            assert d[1] < 0
+    # entering glass never reflects totally
+    assert oracle.refract((math.sin(1.5), -math.cos(1.5), 0), (0, 0, 0), (0, 1, 0), 1 / 1.5) is not None
+
+
+def test_schlick(oracle):
+    """src/trace.rs:144-149: r0 = ((eta-1)/(eta+1))^2 at normal incidence, 1 at grazing."""
+    for eta in (1.5, 1 / 1.5, 1.33):
+        r0 = ((eta - 1) / (eta + 1)) ** 2
+        assert oracle.schlick(eta, 1.0) == pytest.approx(r0, rel=1e-6)
+        assert oracle.schlick(eta, 0.0) == pytest.approx(1.0, rel=1e-6)
+        assert oracle.schlick(eta, 0.5) == pytest.approx(r0 + (1 - r0) * 0.5 ** 5, rel=1e-6)
+
+
+# ------------------------------------------------------------------- sampling
+def test_cosine_sample_is_in_upper_hemisphere_and_unit(oracle):
+    """src/random.rs:33-53."""
+    rng = np.random.default_rng(0)
+    for n in [(0, 1, 0), (0, 0, -1), (0.6, 0.0, 0.8), (0.26726124, 0.5345225, 0.8017837)]:
+        acc = np.zeros(3)
+        for _ in range(400):
+            w = rng.integers(0, 2 ** 32, size=2, dtype=np.uint64)
+            d = np.array(oracle.cosine_sample(n, int(w[0]), int(w[1])))
+            assert abs(np.linalg.norm(d) - 1) < 1e-5
+            assert np.dot(d, n) >= -1e-6
+            acc += d
+        # mean direction of a cosine lobe is (2/3) n
+        assert np.allclose(acc / 400, np.array(n) * 2 / 3, atol=0.12)
+
+
+def test_cosine_sample_degenerate_frame_is_nan(oracle):
+    """Quirk: when |n.x| = |n.y| = |n.z| the helper axis (1,1,1) is parallel to n and the
+    frame is 0/0 (src/random.rs:42-48)."""
+    v = 1 / math.sqrt(3)
+    d = oracle.cosine_sample((v, v, v), 123456789, 987654321)
+    assert all(math.isnan(x) or abs(x) > 0 for x in d)
+
+
+def test_box_light_sampling_never_picks_x_faces(oracle):
+    """Quirk: the third branch of src/objects/sample.rs:31-37 returns z again."""
+    sc = reference_scene()
+    rng = np.random.default_rng(1)
+    faces = {"y": 0, "z": 0}
+    for _ in range(600):
+        w = [int(x) for x in rng.integers(0, 2 ** 32, size=4, dtype=np.uint64)]
+        p = np.array(oracle.light_sample(sc, 5, w)) - np.array([0, 5, 0])
+        assert abs(p[0]) < 2.0                    # never on the |x| = 2 faces (interior draw is [-2, 2))
+        on_y, on_z = abs(abs(p[1]) - 0.1) < 1e-6, abs(abs(p[2]) - 2.0) < 1e-6
+        assert on_y != on_z
+        faces["y" if on_y else "z"] += 1
+    a, b, c = 2.0, 0.1, 2.0
+    # y faces get weight ac / (ab + bc + ac), z faces the rest
+    assert faces["y"] / 600 == pytest.approx(a * c / (a * b + b * c + a * c), abs=0.05)
+
+
+def test_ellipsoid_light_sampling_covers_half_the_surface(oracle):
+    """Quirk: phi is drawn from [0, pi) (src/objects/sample.rs:79): local y >= 0 only."""
+    sc = reference_scene()
+    sc.prims[7] = Prim(ELL, (2, 1, 0.5), position=(1, 2, 3), emission=(1, 1, 1))
+    rng = np.random.default_rng(2)
+    for _ in range(300):
+        w = [int(x) for x in rng.integers(0, 2 ** 32, size=4, dtype=np.uint64)]
+        p = np.array(oracle.light_sample(sc, 7, w)) - np.array([1, 2, 3])
+        assert p[1] >= -1e-6
+        assert (p[0] / 2) ** 2 + (p[1] / 1) ** 2 + (p[2] / 0.5) ** 2 == pytest.approx(1.0, abs=1e-5)
+
+
+def test_light_pdf_collects_both_sides(oracle):
+    """src/random.rs:83-109: a ray through the light box adds the near and the far face:
+    pdf = area_pdf * (t1^2/cos + t2^2/cos) / n_lights with area_pdf = 1/(8(ab+bc+ac))."""
+    sc = reference_scene()
+    p = (0.0, 0.0, 0.0)
+    pdf = oracle.light_pdf(sc, p, (0, 1, 0))
+    area_pdf = 1 / (8 * (2 * 0.1 + 0.1 * 2 + 2 * 2))
+    t1, t2 = 4.9, 5.1
+    assert pdf == pytest.approx(area_pdf * (t1 ** 2 + t2 ** 2), rel=1e-4)
+    assert oracle.light_pdf(sc, p, (0, -1, 0)) == 0.0
+    # MIS mixes 50/50 with the cosine pdf (src/random.rs:143-161)
+    n = (0.0, 1.0, 0.0)
+    assert oracle.mis_pdf(sc, p, n, (0, 1, 0)) == pytest.approx(0.5 / math.pi + 0.5 * pdf, rel=1e-5)
+    # without lights the mixture is the cosine pdf alone
+    nolight = sc.replace(prims=sc.prims[:5])
+    assert oracle.mis_pdf(nolight, p, n, (0, 1, 0)) == pytest.approx(1 / math.pi, rel=1e-6)
+
+
+# -------------------------------------------------------------- whole renders
+def test_light_pixels_tonemap_to_245(oracle):
+    """A primary hit on the light returns exactly (2,2,2) in every sample (the light's
+    albedo is 0); ACES + gamma + byte conversion (src/image.rs:60-79, :44) give 245."""
+    sc = reference_scene(width=64, height=64, n_samples=3)
+    ids, *_ = oracle.primary(sc)
+    img = oracle.render(sc, seed=5)
+    from scipy.ndimage import binary_erosion
+    core = binary_erosion(ids == 5, iterations=1)
+    assert core.sum() >= 4
+    assert np.all(img[core] == 2.0)
+    assert np.all(oracle.to_bytes(oracle.color_correction(img[core])) == 245)
+
+
+def test_depth_cut_returns_zero_before_intersecting(oracle):
+    """src/trace.rs:12-14: with RAY_DEPTH 1 only directly visible emission is seen."""
+    sc = reference_scene(width=32, height=32, n_samples=2, ray_depth=1)
+    ids, *_ = oracle.primary(sc)
+    img = oracle.render(sc, seed=1)
+    from scipy.ndimage import binary_erosion, binary_dilation
+    assert np.all(img[binary_erosion(ids == 5)] == 2.0)
+    assert np.all(img[~binary_dilation(ids == 5, iterations=2)] == 0.0)
+    assert np.all(oracle.render(sc.replace(ray_depth=0), seed=1) == 0.0)
+
+
+@pytest.mark.parametrize("scene_fn", [reference_scene, dielectric_scene])
+def test_forward_order_matches_reference_order(oracle, scene_fn):
+    """Front-to-back accumulation + sum/N agree with recursion + running mean
+    (src/main.rs:23-27, src/trace.rs:48,70) within 1e-5 relative."""
+    sc = scene_fn(width=48, height=36, n_samples=6)
+    a = oracle.render(sc, seed=9, order=oracle.ORDER_REFERENCE)
+    b = oracle.render(sc, seed=9, order=oracle.ORDER_FORWARD)
+    err = np.abs(a - b) / np.maximum(np.maximum(np.abs(a), np.abs(b)), 1e-6)
+    assert err.max() <= 1e-5
+    assert a.max() > 0
+
+
+def test_sample_ranges_partition_the_sum(oracle):
+    sc = reference_scene(width=24, height=16, n_samples=7)
+    parts = [oracle.render(sc, seed=3, order=oracle.ORDER_FORWARD, sample_first=f, sample_count=c, output_sum=True)
+             for f, c in ((0, 3), (3, 4))]
+    full = oracle.render(sc, seed=3, order=oracle.ORDER_FORWARD)
+    assert np.allclose((parts[0] + parts[1]) / 7, full, rtol=1e-6, atol=0)
+
+
+def test_seed_changes_the_image_and_same_seed_repeats(oracle):
+    sc = reference_scene(width=16, height=16, n_samples=2)
+    a, b, c = oracle.render(sc, seed=1), oracle.render(sc, seed=1), oracle.render(sc, seed=2)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+def test_golden_fixture(oracle):
+    """The committed fixture (tests/golden/make_golden.py wrote it with this oracle) guards
+    against accidental changes of the oracle itself."""
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "reference_scene_64x64.npz")
+    g = np.load(path)
+    sc = reference_scene(width=64, height=64, n_samples=4)
+    ids, t, n, ins = oracle.primary(sc)
+    assert np.array_equal(ids, g["hit_id"]) and np.array_equal(t, g["t"]) and np.array_equal(n, g["normal"])
+    img = oracle.render(sc, seed=1, order=oracle.ORDER_REFERENCE)
+    assert np.array_equal(img, g["radiance_seed1_4spp"])
+    cx = oracle.render(sc, order=oracle.ORDER_REFERENCE, rng_mode=oracle.RNG_CONST,
+                       const_words=tuple(int(x) for x in g["const_words"]))
+    assert np.array_equal(cx, g["radiance_const_xi"])
