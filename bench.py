@@ -160,7 +160,7 @@ def main():
     rays_total = None
     roofline = None
     if stats is not None:
-        flops_rank = algorithmic_flops(stats)
+        flops_rank = algorithmic_flops(stats, stats.get("bvh_node_tests", 0))
         achieved = flops_rank / (kernel_ms * 1e-3) / 1e12
         roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,

@@ -111,6 +111,7 @@ typedef struct rtx_stats {
     uint64_t dielectric_bounces;
     uint64_t prim_tests[3];    /* object intersect calls in closest-hit queries by kind */
     uint64_t light_tests[3];   /* light intersect calls in light-pdf evaluation by kind */
+    uint64_t bvh_node_tests;   /* node-box tests of the BVH traversal (0 for the linear scan) */
 } rtx_stats;
 
 typedef struct rtx_ctx rtx_ctx;

@@ -80,6 +80,7 @@ class rtx_stats(C.Structure):
         ("dielectric_bounces", C.c_uint64),
         ("prim_tests", C.c_uint64 * 3),
         ("light_tests", C.c_uint64 * 3),
+        ("bvh_node_tests", C.c_uint64),
     ]
 
     def as_dict(self):

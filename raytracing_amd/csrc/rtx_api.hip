@@ -203,7 +203,7 @@ int upload_scene(rtx_ctx *c)
     P.bvh.nodes = reinterpret_cast<const float4 *>(base + off_nodes);
     P.bvh.prim_index = reinterpret_cast<const int32_t *>(base + off_pidx);
     P.bvh.planes = reinterpret_cast<const int32_t *>(base + off_planes);
-    P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / 2);
+    P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / 4);
     P.bvh.n_planes = (uint32_t)bvh.planes.size();
     return RTX_OK;
 }
@@ -239,11 +239,16 @@ void stats_from_counters(const rtx_ctx *c, const unsigned long long *v, rtx_stat
     s->dielectric_bounces = v[rtx::C_DIELECTRIC];
     s->light_tests[1] = v[rtx::C_LTEST_ELLIPSOID];
     s->light_tests[2] = v[rtx::C_LTEST_BOX];
-    // a brute-force closest-hit query tests every object once
     if (c->src != rtx::kSrcBvh) {
+        // a brute-force closest-hit query tests every object once
         uint64_t per_kind[3] = {0, 0, 0};
         for (const rtx_prim &p : c->prims) per_kind[p.kind]++;
         for (int k = 0; k < 3; ++k) s->prim_tests[k] = s->rays * per_kind[k];
+    } else {
+        s->prim_tests[0] = v[rtx::C_PTEST_PLANE];
+        s->prim_tests[1] = v[rtx::C_PTEST_ELLIPSOID];
+        s->prim_tests[2] = v[rtx::C_PTEST_BOX];
+        s->bvh_node_tests = v[rtx::C_NODE_TESTS];
     }
 }
 

@@ -1,13 +1,264 @@
-// rtx_bvh.cpp -- BVH construction (host).
+// rtx_bvh.cpp -- BVH construction on the host: binned surface-area heuristic, binary tree,
+// leaves of up to kBvhLeafSize objects, depth capped at kBvhMaxDepth (deeper subtrees become
+// one large leaf), nodes emitted breadth-first.
 #include "rtx_bvh.h"
 
-namespace rtx {
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <queue>
 
-void build_bvh(const rtx_prim *, uint32_t, BvhHost &out)
+namespace rtx {
+namespace {
+
+struct Box3 {
+    double lo[3], hi[3];
+    void clear()
+    {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::numeric_limits<double>::infinity();
+            hi[k] = -std::numeric_limits<double>::infinity();
+        }
+    }
+    void grow(const Box3 &b)
+    {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], b.lo[k]);
+            hi[k] = std::max(hi[k], b.hi[k]);
+        }
+    }
+    double half_area() const
+    {
+        double e[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        if (e[0] < 0 || e[1] < 0 || e[2] < 0) return 0.0;
+        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+    }
+};
+
+struct Ref {
+    Box3 box;
+    double c[3];
+    int32_t prim;
+};
+
+// World bounds of a rotated ellipsoid / box, or false when they cannot be trusted.
+bool world_bounds(const rtx_prim &p, Box3 &out)
+{
+    double q[4] = {p.rotation[0], p.rotation[1], p.rotation[2], p.rotation[3]};
+    double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+    if (!std::isfinite(n2) || n2 <= 0.0) return false;
+    // the device rotates with the quaternion as stored; a non-unit quaternion scales by
+    // up to (|w| + |u|)^2, so bound the matrix entries with that factor
+    double x = q[0], y = q[1], z = q[2], w = q[3];
+    double R[3][3] = {{w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)},
+                      {2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)},
+                      {2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z}};
+    double scale = std::max(1.0, n2);
+    double maxc = 0.0, maxe = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        if (!std::isfinite(p.position[k]) || !std::isfinite(p.param[k])) return false;
+        maxc = std::max(maxc, std::fabs((double)p.position[k]));
+    }
+    double e[3];
+    for (int k = 0; k < 3; ++k) {
+        double s = 0.0;
+        for (int j = 0; j < 3; ++j) {
+            double a = std::fabs(R[k][j]) * std::fabs((double)p.param[j]);
+            s += (p.kind == RTX_ELLIPSOID) ? a * a : a;
+        }
+        e[k] = (p.kind == RTX_ELLIPSOID ? std::sqrt(s) : s) * scale;
+        maxe = std::max(maxe, e[k]);
+    }
+    // padding: f32 rounding of the exact test is ~1e-6 of the coordinates involved
+    double pad = 1e-4 * (1.0 + maxc + maxe);
+    for (int k = 0; k < 3; ++k) {
+        out.lo[k] = (double)p.position[k] - e[k] * (1.0 + 1e-5) - pad;
+        out.hi[k] = (double)p.position[k] + e[k] * (1.0 + 1e-5) + pad;
+        if (!std::isfinite(out.lo[k]) || !std::isfinite(out.hi[k])) return false;
+    }
+    return true;
+}
+
+struct BuildNode {
+    Box3 box[2];
+    int32_t child[2];  // inner: index into the build-node array; leaf: first slot
+    int32_t count[2];  // 0 = inner (or empty when child < 0)
+};
+
+struct Builder {
+    std::vector<Ref> refs;
+    std::vector<BuildNode> nodes;
+    std::vector<int32_t> slots;
+    int depth = 0;
+
+    // returns (child, count) describing refs[b, e)
+    void make(size_t b, size_t e, int level, int32_t &child, int32_t &count)
+    {
+        depth = std::max(depth, level);
+        const size_t n = e - b;
+        if (n <= (size_t)kBvhLeafSize || level >= kBvhMaxDepth) {
+            child = (int32_t)slots.size();
+            count = (int32_t)n;
+            for (size_t i = b; i < e; ++i) slots.push_back(refs[i].prim);
+            // keep leaf objects in index order: ties resolve towards the lowest index sooner
+            std::sort(slots.end() - (ptrdiff_t)n, slots.end());
+            return;
+        }
+        size_t mid = split(b, e);
+        int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        BuildNode tmp;
+        tmp.box[0].clear();
+        tmp.box[1].clear();
+        for (size_t i = b; i < mid; ++i) tmp.box[0].grow(refs[i].box);
+        for (size_t i = mid; i < e; ++i) tmp.box[1].grow(refs[i].box);
+        make(b, mid, level + 1, tmp.child[0], tmp.count[0]);
+        make(mid, e, level + 1, tmp.child[1], tmp.count[1]);
+        nodes[(size_t)me] = tmp;
+        child = me;
+        count = 0;
+    }
+
+    size_t split(size_t b, size_t e)
+    {
+        Box3 cb;
+        cb.clear();
+        for (size_t i = b; i < e; ++i)
+            for (int k = 0; k < 3; ++k) {
+                cb.lo[k] = std::min(cb.lo[k], refs[i].c[k]);
+                cb.hi[k] = std::max(cb.hi[k], refs[i].c[k]);
+            }
+        constexpr int kBins = 16;
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_axis = -1, best_bin = -1;
+        for (int axis = 0; axis < 3; ++axis) {
+            double ext = cb.hi[axis] - cb.lo[axis];
+            if (!(ext > 0.0)) continue;
+            Box3 bb[kBins];
+            size_t cnt[kBins];
+            for (int i = 0; i < kBins; ++i) { bb[i].clear(); cnt[i] = 0; }
+            for (size_t i = b; i < e; ++i) {
+                int bi = std::min(kBins - 1, (int)((refs[i].c[axis] - cb.lo[axis]) / ext * kBins));
+                bb[bi].grow(refs[i].box);
+                cnt[bi]++;
+            }
+            double right_area[kBins];
+            size_t right_cnt[kBins];
+            Box3 acc;
+            acc.clear();
+            size_t c = 0;
+            for (int i = kBins - 1; i > 0; --i) {
+                acc.grow(bb[i]);
+                c += cnt[i];
+                right_area[i] = acc.half_area();
+                right_cnt[i] = c;
+            }
+            acc.clear();
+            c = 0;
+            for (int i = 0; i < kBins - 1; ++i) {
+                acc.grow(bb[i]);
+                c += cnt[i];
+                if (c == 0 || right_cnt[i + 1] == 0) continue;
+                double cost = acc.half_area() * (double)c + right_area[i + 1] * (double)right_cnt[i + 1];
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = i; }
+            }
+        }
+        size_t mid;
+        if (best_axis >= 0) {
+            double ext = cb.hi[best_axis] - cb.lo[best_axis];
+            double lo = cb.lo[best_axis];
+            auto it = std::partition(refs.begin() + (ptrdiff_t)b, refs.begin() + (ptrdiff_t)e, [&](const Ref &r) {
+                int bi = std::min(kBins - 1, (int)((r.c[best_axis] - lo) / ext * kBins));
+                return bi <= best_bin;
+            });
+            mid = (size_t)(it - refs.begin());
+        } else {
+            mid = b;
+        }
+        if (mid == b || mid == e) {
+            // all centres coincide (or binning failed): split by object index
+            mid = b + (e - b) / 2;
+            std::nth_element(refs.begin() + (ptrdiff_t)b, refs.begin() + (ptrdiff_t)mid, refs.begin() + (ptrdiff_t)e,
+                             [](const Ref &x, const Ref &y) { return x.prim < y.prim; });
+        }
+        return mid;
+    }
+};
+
+float round_down(double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -INFINITY) : f; }
+float round_up(double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; }
+float int_bits(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
+
+}  // namespace
+
+void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
 {
     out.nodes.clear();
     out.prim_index.clear();
     out.planes.clear();
+    out.depth = 0;
+    Builder bld;
+    for (uint32_t i = 0; i < n; ++i) {
+        Ref r;
+        r.prim = (int32_t)i;
+        if (prims[i].kind == RTX_PLANE || !world_bounds(prims[i], r.box)) {
+            out.planes.push_back((int32_t)i);
+            continue;
+        }
+        for (int k = 0; k < 3; ++k) r.c[k] = 0.5 * (r.box.lo[k] + r.box.hi[k]);
+        bld.refs.push_back(r);
+    }
+    if (bld.refs.empty()) return;
+
+    int32_t root_child, root_count;
+    bld.make(0, bld.refs.size(), 0, root_child, root_count);
+    if (root_count > 0) {
+        // everything fits one leaf: a single node whose first child is that leaf
+        BuildNode nd;
+        nd.box[0].clear();
+        nd.box[1].clear();
+        for (const Ref &r : bld.refs) nd.box[0].grow(r.box);
+        nd.child[0] = root_child;
+        nd.count[0] = root_count;
+        nd.child[1] = -1;
+        nd.count[1] = 0;
+        bld.nodes.push_back(nd);
+        root_child = (int32_t)bld.nodes.size() - 1;
+    }
+    // breadth-first renumbering
+    std::vector<int32_t> order, new_index(bld.nodes.size(), -1);
+    std::queue<int32_t> q;
+    q.push(root_child);
+    while (!q.empty()) {
+        int32_t i = q.front();
+        q.pop();
+        new_index[(size_t)i] = (int32_t)order.size();
+        order.push_back(i);
+        for (int c = 0; c < 2; ++c)
+            if (bld.nodes[(size_t)i].count[c] == 0 && bld.nodes[(size_t)i].child[c] >= 0) q.push(bld.nodes[(size_t)i].child[c]);
+    }
+    out.nodes.resize(order.size() * 4);
+    for (size_t k = 0; k < order.size(); ++k) {
+        const BuildNode &nd = bld.nodes[(size_t)order[k]];
+        float lo[2][3], hi[2][3];
+        for (int c = 0; c < 2; ++c)
+            for (int a = 0; a < 3; ++a) {
+                lo[c][a] = round_down(nd.box[c].lo[a]);
+                hi[c][a] = round_up(nd.box[c].hi[a]);
+            }
+        int32_t ch[2], cn[2];
+        for (int c = 0; c < 2; ++c) {
+            cn[c] = nd.count[c];
+            ch[c] = (nd.count[c] == 0 && nd.child[c] >= 0) ? new_index[(size_t)nd.child[c]] : nd.child[c];
+        }
+        out.nodes[4 * k + 0] = make_float4(lo[0][0], lo[0][1], lo[0][2], hi[0][0]);
+        out.nodes[4 * k + 1] = make_float4(hi[0][1], hi[0][2], lo[1][0], lo[1][1]);
+        out.nodes[4 * k + 2] = make_float4(lo[1][2], hi[1][0], hi[1][1], hi[1][2]);
+        out.nodes[4 * k + 3] = make_float4(int_bits(ch[0]), int_bits(cn[0]), int_bits(ch[1]), int_bits(cn[1]));
+    }
+    out.prim_index = bld.slots;
+    out.depth = bld.depth;
 }
 
 }  // namespace rtx

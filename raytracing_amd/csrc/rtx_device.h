@@ -23,11 +23,12 @@ enum : int { kDiffuse = 0, kMetallic = 1, kDielectric = 2 };
 enum : int {
     C_SAMPLES = 0, C_RAYS, C_HIT_PLANE, C_HIT_ELLIPSOID, C_HIT_BOX, C_COSINE,
     C_LSAMPLE_ELLIPSOID, C_LSAMPLE_BOX, C_PDF_EVALS, C_LPDF_0, C_LPDF_1, C_LPDF_2,
-    C_DIFFUSE, C_METALLIC, C_DIELECTRIC, C_LTEST_ELLIPSOID, C_LTEST_BOX, C_COUNT
+    C_DIFFUSE, C_METALLIC, C_DIELECTRIC, C_LTEST_ELLIPSOID, C_LTEST_BOX,
+    C_PTEST_PLANE, C_PTEST_ELLIPSOID, C_PTEST_BOX, C_NODE_TESTS, C_COUNT
 };
 
 struct BvhView {
-    const float4 *nodes;   // 2 float4 per node, see rtx_bvh.h
+    const float4 *nodes;   // 4 float4 per node, see rtx_bvh.h
     const int32_t *prim_index; // leaf slots -> object index
     const int32_t *planes; // objects that are tested for every ray
     uint32_t n_nodes, n_planes;

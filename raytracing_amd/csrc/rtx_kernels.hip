@@ -62,10 +62,10 @@ RTX_DEV bool lane_pixel(const RenderParams &P, uint32_t &px, uint32_t &py)
     return px < P.width && py < P.height;
 }
 
-template <int SRC>
-RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, float &t)
+template <int SRC, bool STATS>
+RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, float &t, Counters<STATS> &cnt)
 {
-    if constexpr (SRC == kSrcBvh) return closest_hit_bvh(P.bvh, tab, o, d, t);
+    if constexpr (SRC == kSrcBvh) return closest_hit_bvh<STATS>(P.bvh, tab, o, d, t, cnt);
     else return closest_hit_scan<true>(tab, o, d, t);
 }
 
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(256) k_megakernel(const RenderParams P)
         }
         cnt.template add<C_RAYS>();
         float t;
-        int idx = closest_hit<SRC>(P, tab, p.o, p.d, t);
+        int idx = closest_hit<SRC, STATS>(P, tab, p.o, p.d, t, cnt);
         bool done;
         if (idx < 0) {
             p.L = p.L + cmul(p.T, bg);
@@ -139,7 +139,8 @@ __global__ void __launch_bounds__(256) k_primary(const RenderParams P, const Pri
     V3 o, d;
     camera_ray(P, px, P.height - 1u - py, 0.5f, 0.5f, o, d);
     float t;
-    int idx = closest_hit<SRC>(P, tab, o, d, t);
+    Counters<false> cnt;
+    int idx = closest_hit<SRC, false>(P, tab, o, d, t, cnt);
     Hit h;
     h.n = v3(0.0f, 0.0f, 0.0f);
     h.inside = false;
