@@ -5,6 +5,7 @@
 #include "../../include/rtx.h"
 #include "rtx_bvh.h"
 #include "rtx_device.h"
+#include "rtx_wavefront.h"
 
 #include <hip/hip_runtime.h>
 
@@ -71,6 +72,9 @@ struct rtx_ctx {
     // scratch owned by the context
     float *d_image = nullptr;
     size_t d_image_floats = 0;
+    void *d_wavefront = nullptr;  // path state + queues of the wavefront variant
+    size_t d_wavefront_bytes = 0;
+    uint32_t wavefront_iterations = 0;
     unsigned long long *d_stats = nullptr;
     rtx_stats stats{};
     bool stats_valid = false;
@@ -296,6 +300,7 @@ void rtx_destroy(rtx_ctx *c)
     DeviceGuard g(c->device);
     free_scene(c);
     if (c->d_image) (void)hipFree(c->d_image);
+    if (c->d_wavefront) (void)hipFree(c->d_wavefront);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -325,8 +330,6 @@ int rtx_set_scene(rtx_ctx *c, const rtx_scene *s)
     case RTX_ACCEL_BRUTE_SCALAR: c->src = rtx::kSrcScalar; break;
     default: c->src = rtx::kSrcBvh; break;
     }
-    if (c->opts.mode == RTX_MODE_WAVEFRONT && c->src == rtx::kSrcBvh)
-        return fail(RTX_ERR_UNSUPPORTED, "the wavefront variant scans the object table; BVH is megakernel-only");
     rc = upload_scene(c);
     if (rc != RTX_OK) return rc;
     c->have_scene = true;
@@ -352,7 +355,18 @@ int rtx_render_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count,
     if (stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, rtx::C_COUNT * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(c->ev_start, stream));
     if (c->opts.mode == RTX_MODE_WAVEFRONT) {
-        return fail(RTX_ERR_UNSUPPORTED, "wavefront mode is not available in this build");
+        const uint32_t n_pixels = P.width * P.height;
+        const size_t need = rtx::wavefront_state_bytes(n_pixels);
+        if (c->d_wavefront_bytes < need) {
+            if (c->d_wavefront) (void)hipFree(c->d_wavefront);
+            c->d_wavefront = nullptr;
+            c->d_wavefront_bytes = 0;
+            HIP_TRY(hipMalloc(&c->d_wavefront, need));
+            c->d_wavefront_bytes = need;
+        }
+        rtx::WfState S;
+        rtx::wavefront_bind_state(c->d_wavefront, n_pixels, S);
+        HIP_TRY(rtx::launch_wavefront(P, S, c->src, stats, stream, &c->wavefront_iterations));
     } else {
         HIP_TRY(rtx::launch_megakernel(P, c->src, stats, stream));
     }

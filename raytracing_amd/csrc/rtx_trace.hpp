@@ -367,19 +367,26 @@ RTX_DEV void camera_ray(const RenderParams &P, uint32_t i, uint32_t j, float du,
     d = normalize(dir);
 }
 
-// One surface interaction at object `idx`, distance t along the path's ray: adds the
-// emission, then scatters.  Returns true when the path ends here.  The scatter at the
-// last allowed depth is skipped: its child ray would be cut before intersecting
-// (src/trace.rs:12-14) and contribute zero.
+// Emission of the object that was hit (src/trace.rs:23,70).  Returns true when the path
+// ends here because its child ray would be cut before intersecting (src/trace.rs:12-14):
+// the scatter at the last allowed depth multiplies a zero and is skipped.
+RTX_DEV bool surface_emission(const RenderParams &P, const Table &tab, Path &p, int idx)
+{
+    float4 m1 = tab.mat[2 * idx + 1];
+    p.L = p.L + cmul(p.T, v3(m1.x, m1.y, m1.z));
+    return p.depth + 1 >= P.ray_depth;
+}
+
+// The material switch of src/trace.rs:25-68 at object `idx`, distance t along the path's
+// ray: picks the next ray and updates the throughput.  Returns true when the path ends
+// here (a rejected diffuse sample).  `material` is the object's material; kernels that
+// run one material per launch pass it as a constant.
 template <bool STATS>
-RTX_DEV bool scatter(const RenderParams &P, const Table &tab, Path &p, int idx, float t,
-                     uint32_t pixel, uint32_t sample, Counters<STATS> &cnt)
+RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, float t, int material,
+                    uint32_t pixel, uint32_t sample, Counters<STATS> &cnt)
 {
     float4 m0 = tab.mat[2 * idx + 0], m1 = tab.mat[2 * idx + 1];
-    V3 color = v3(m0.x, m0.y, m0.z), emission = v3(m1.x, m1.y, m1.z);
-    int material = __float_as_int(m0.w);
-    p.L = p.L + cmul(p.T, emission);
-    if (p.depth + 1 >= P.ray_depth) return true;
+    V3 color = v3(m0.x, m0.y, m0.z);
 
     Hit h = finish_hit(tab, idx, p.o, p.d, t, material == kDielectric);
     V3 point = p.o + p.d * t;
@@ -441,6 +448,16 @@ RTX_DEV bool scatter(const RenderParams &P, const Table &tab, Path &p, int idx, 
     }
     p.depth += 1;
     return false;
+}
+
+// One whole surface interaction (emission, depth cut, material switch); true = path ended.
+template <bool STATS>
+RTX_DEV bool scatter(const RenderParams &P, const Table &tab, Path &p, int idx, float t,
+                     uint32_t pixel, uint32_t sample, Counters<STATS> &cnt)
+{
+    if (surface_emission(P, tab, p, idx)) return true;
+    int material = __float_as_int(tab.mat[2 * idx + 0].w);
+    return bounce<STATS>(P, tab, p, idx, t, material, pixel, sample, cnt);
 }
 
 }  // namespace rtx
