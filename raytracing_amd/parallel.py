@@ -33,7 +33,7 @@ def render_distributed(renderer, scene, buf, process_group=None):
     world = dist.get_world_size(process_group) if dist.is_initialized() else 1
     rank = dist.get_rank(process_group) if dist.is_initialized() else 0
     first, count = sample_range(scene.n_samples, rank, world)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = torch.cuda.current_stream(buf.device).cuda_stream if buf.is_cuda else 0
     renderer.set_scene(scene)
     if count > 0:
         renderer.render_samples(first, count, buf.data_ptr(), stream)
