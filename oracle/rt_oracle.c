@@ -12,7 +12,7 @@
  *   M*v           = ((col0*v.x) + col1*v.y) + col2*v.z   per component
  *   q*v           = ((t*q.w) + cross(q.xyz,t)) + v,  t = cross(q.xyz,v)*2
  *   q.inverse()   = conjugate
- *   f32::min/max  ignore a NaN operand; argmax = first strict maximum
+ *   f32::min/max  ignore a NaN operand, -0 < +0; argmax = first strict maximum
  *   gen::<f32>()  = (u32 >> 8) * 2^-24;  gen_range(lo..hi) = ((u32 >> 9) * 2^-23) * (hi-lo) + lo
  *   gen_bool(0.5) = top bit of the draw is 0
  *
@@ -61,9 +61,23 @@ static inline v3 cross3(v3 a, v3 b)
 {
     return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
-/* f32::min / f32::max: a NaN operand is ignored */
-static inline float rmin(float a, float b) { return (a != a) ? b : ((b < a) ? b : a); }
-static inline float rmax(float a, float b) { return (a != a) ? b : ((b > a) ? b : a); }
+/* f32::min / f32::max: a NaN operand is ignored.  For operands that compare equal (+0 and
+ * -0) the language leaves the choice open; -0 is taken as the smaller, as the IEEE
+ * minimumNumber / maximumNumber operations (and the GPU's v_min_f32 / v_max_f32) do. */
+static inline float rmin(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return signbit(a) ? a : b;
+    return (b < a) ? b : a;
+}
+static inline float rmax(float a, float b)
+{
+    if (a != a) return b;
+    if (b != b) return a;
+    if (a == b) return signbit(a) ? b : a;
+    return (b > a) ? b : a;
+}
 static inline int is_finite_f(float x) { return (x - x) == 0.0f; }
 
 /* unit quaternion (x,y,z,w) times vector */

@@ -107,6 +107,18 @@ void derive_lights(const std::vector<rtx_prim> &prims, std::vector<int32_t> &out
     }
 }
 
+// rotation exactly (+0, +0, +0, 1) and a finite, moderate position: the device may skip
+// the two rotations of such an object for plain rays (rtx_trace.hpp: ray_is_plain)
+bool is_identity_pose(const rtx_prim &p)
+{
+    uint32_t q[4];
+    std::memcpy(q, p.rotation, sizeof(q));
+    if (q[0] != 0u || q[1] != 0u || q[2] != 0u || q[3] != 0x3f800000u) return false;
+    for (int k = 0; k < 3; ++k)
+        if (!(std::fabs(p.position[k]) < 1e30f)) return false;
+    return true;
+}
+
 int validate_scene(const rtx_scene *s)
 {
     if (!s) return fail(RTX_ERR_INVALID_ARG, "scene is null");
@@ -138,7 +150,7 @@ int upload_scene(rtx_ctx *c)
     const size_t n = c->prims.size();
     const size_t nl = c->lights.size();
     const size_t geom_bytes = align16(n * 3 * sizeof(float4));
-    const size_t mat_bytes = align16(n * 2 * sizeof(float4));
+    const size_t mat_bytes = align16(n * 3 * sizeof(float4));
     const size_t light_bytes = align16(nl * sizeof(int32_t));
 
     rtx::BvhHost bvh;
@@ -155,15 +167,26 @@ int upload_scene(rtx_ctx *c)
     int32_t *lights = reinterpret_cast<int32_t *>(host.data() + geom_bytes + mat_bytes);
     for (size_t i = 0; i < n; ++i) {
         const rtx_prim &p = c->prims[i];
-        int32_t kind = (int32_t)p.kind, material = (int32_t)p.material;
+        int32_t kind = (int32_t)p.kind | (is_identity_pose(p) ? (rtx::kGeomIdentity << 8) : 0);
+        int32_t material = (int32_t)p.material;
         float kind_bits, mat_bits;
         std::memcpy(&kind_bits, &kind, 4);
         std::memcpy(&mat_bits, &material, 4);
         geom[3 * i + 0] = make_float4(p.rotation[0], p.rotation[1], p.rotation[2], p.rotation[3]);
         geom[3 * i + 1] = make_float4(p.position[0], p.position[1], p.position[2], kind_bits);
         geom[3 * i + 2] = make_float4(p.param[0], p.param[1], p.param[2], 0.0f);
-        mat[2 * i + 0] = make_float4(p.color[0], p.color[1], p.color[2], mat_bits);
-        mat[2 * i + 1] = make_float4(p.emission[0], p.emission[1], p.emission[2], p.ior);
+        mat[3 * i + 0] = make_float4(p.color[0], p.color[1], p.color[2], mat_bits);
+        mat[3 * i + 1] = make_float4(p.emission[0], p.emission[1], p.emission[2], p.ior);
+        // src/trace.rs:27 (color / PI) and src/objects/sample.rs:53-57 (box surface pdf) depend on
+        // the object only: evaluated here once, with the same IEEE operations
+        const float pi = 3.14159274101257324f;
+        float area_pdf = 0.0f;
+        if (p.kind == RTX_BOX) {
+            float a = p.param[0], b = p.param[1], cc = p.param[2];
+            float area = 8.0f * ((a * b + b * cc) + a * cc);
+            area_pdf = 1.0f / area;
+        }
+        mat[3 * i + 2] = make_float4(p.color[0] / pi, p.color[1] / pi, p.color[2] / pi, area_pdf);
     }
     for (size_t i = 0; i < nl; ++i) lights[i] = c->lights[i];
     size_t off_nodes = geom_bytes + mat_bytes + light_bytes;

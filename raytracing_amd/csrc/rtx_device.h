@@ -2,10 +2,12 @@
 //
 // Device scene layout (one hipMalloc block, all arrays 16-byte aligned):
 //   geom[3*i+0] = rotation quaternion (x, y, z, w)          \  the 48 bytes a closest-hit
-//   geom[3*i+1] = position xyz, kind (int bits) in w          > scan reads per object
+//   geom[3*i+1] = position xyz, kind | flags << 8 (int bits)   > scan reads per object
 //   geom[3*i+2] = param xyz (normal | radii | half-sizes), 0 /
-//   mat[2*i+0]  = color rgb, material (int bits) in w        \  the 32 bytes shading reads
-//   mat[2*i+1]  = emission rgb, ior in w                     /  for the object that was hit
+//   mat[3*i+0]  = color rgb, material (int bits) in w        \  the 48 bytes shading reads
+//   mat[3*i+1]  = emission rgb, ior in w                      > for the object that was hit
+//   mat[3*i+2]  = color / pi (IEEE division at upload),      /
+//                 w = 1 / (8 (ab + bc + ac)) for a box (its surface pdf), else 0
 //   lights[k]   = object index of light k (emissive ellipsoids and boxes, object order)
 // The scan data and the shading data are separate arrays so that the scan streams 48
 // contiguous bytes per object and never touches colours.
@@ -18,6 +20,7 @@ namespace rtx {
 
 enum : int { kPlane = 0, kEllipsoid = 1, kBox = 2 };
 enum : int { kDiffuse = 0, kMetallic = 1, kDielectric = 2 };
+enum : int { kGeomIdentity = 1 };  // Geom::flags
 
 // event counters kept per lane when statistics are requested
 enum : int {

@@ -19,14 +19,14 @@ extern __shared__ float4 rtx_smem[];
 
 size_t scene_lds_bytes(uint32_t n_prims, uint32_t n_lights)
 {
-    size_t b = (size_t)n_prims * 5u * sizeof(float4) + (size_t)n_lights * sizeof(int32_t);
+    size_t b = (size_t)n_prims * 6u * sizeof(float4) + (size_t)n_lights * sizeof(int32_t);
     return (b + 15u) & ~(size_t)15u;
 }
 
 // copies the object table into LDS; every thread of the workgroup must call it
 RTX_DEV Table stage_table_lds(const RenderParams &P)
 {
-    const uint32_t ng = 3u * P.n_prims, nm = 2u * P.n_prims;
+    const uint32_t ng = 3u * P.n_prims, nm = 3u * P.n_prims;
     for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) rtx_smem[i] = P.geom[i];
     for (uint32_t i = threadIdx.x; i < nm; i += blockDim.x) rtx_smem[ng + i] = P.mat[i];
     int32_t *sl = reinterpret_cast<int32_t *>(rtx_smem + ng + nm);
@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) k_megakernel(const RenderParams P)
             done = true;
         } else {
             if constexpr (STATS) {
-                int kind = __float_as_int(tab.geom[3 * idx + 1].w);
+                int kind = __float_as_int(tab.geom[3 * idx + 1].w) & 0xff;
                 cnt.template add<C_HIT_PLANE>(kind == kPlane);
                 cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
                 cnt.template add<C_HIT_BOX>(kind == kBox);

@@ -41,10 +41,10 @@ RTX_DEV V3 cross(V3 a, V3 b)
 }
 RTX_DEV float comp(V3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
 
-// f32::min / f32::max of the reference's language: a NaN operand is ignored; on a tie
-// (including +0 / -0) the first operand is kept.
-RTX_DEV float rmin(float a, float b) { return (a != a) ? b : ((b < a) ? b : a); }
-RTX_DEV float rmax(float a, float b) { return (a != a) ? b : ((b > a) ? b : a); }
+// f32::min / f32::max of the reference's language: a NaN operand is ignored; operands that
+// compare equal (+0 / -0) may return either, and v_min_f32 / v_max_f32 order -0 below +0.
+RTX_DEV float rmin(float a, float b) { return __builtin_fminf(a, b); }
+RTX_DEV float rmax(float a, float b) { return __builtin_fmaxf(a, b); }
 RTX_DEV bool finite_f(float x) { return (x - x) == 0.0f; }
 
 // unit quaternion (x, y, z, w) applied to a vector; inverse = conjugate

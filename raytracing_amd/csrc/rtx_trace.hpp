@@ -47,6 +47,7 @@ struct Geom {
     float4 rot;
     V3 pos;
     int kind;
+    int flags;   // kGeomIdentity: rotation is exactly (+0, +0, +0, 1) and the position is tame
     V3 param;
 };
 RTX_DEV Geom load_geom(const float4 *g, uint32_t i)
@@ -55,9 +56,28 @@ RTX_DEV Geom load_geom(const float4 *g, uint32_t i)
     Geom r;
     r.rot = a;
     r.pos = v3(b.x, b.y, b.z);
-    r.kind = __float_as_int(b.w);
+    int bits = __float_as_int(b.w);
+    r.kind = bits & 0xff;
+    r.flags = bits >> 8;
     r.param = v3(c.x, c.y, c.z);
     return r;
+}
+
+// A ray is "plain" when every component of its origin and direction is finite, below 1e30 in
+// magnitude and not -0.  For a plain ray and an object whose rotation is exactly the identity
+// quaternion, the rotation formula returns its argument bit for bit: every product with the
+// quaternion's zero vector part is a zero, a zero added to a non-zero x gives x, and a zero
+// added to +0 gives +0 -- only a -0 component (or a non-finite one, 0 * inf) could come out
+// different, and o - p cannot be -0 unless o is.  Such objects skip the two rotations.
+RTX_DEV bool ray_is_plain(V3 o, V3 d)
+{
+    float m = ((fabsf(o.x) + fabsf(o.y)) + fabsf(o.z)) + ((fabsf(d.x) + fabsf(d.y)) + fabsf(d.z));
+    bool ok = m < 1e30f;
+    ok = ok && __float_as_uint(o.x) != 0x80000000u && __float_as_uint(o.y) != 0x80000000u &&
+         __float_as_uint(o.z) != 0x80000000u;
+    ok = ok && __float_as_uint(d.x) != 0x80000000u && __float_as_uint(d.y) != 0x80000000u &&
+         __float_as_uint(d.z) != 0x80000000u;
+    return ok;
 }
 
 struct LocalRay {
@@ -69,6 +89,14 @@ RTX_DEV LocalRay to_local(const Geom &g, V3 o, V3 d)
     LocalRay r;
     r.o = rotate_inv(g.rot, o - g.pos);
     r.d = rotate_inv(g.rot, d);
+    return r;
+}
+// the same for an identity-rotation object and a plain ray (see ray_is_plain)
+RTX_DEV LocalRay to_local_identity(const Geom &g, V3 o, V3 d)
+{
+    LocalRay r;
+    r.o = o - g.pos;
+    r.d = d;
     return r;
 }
 
@@ -155,9 +183,15 @@ RTX_DEV int closest_hit_scan(const Table &tab, V3 o, V3 d, float &best_t)
     float ray_length = len(d);
     int best = -1;
     best_t = kInf;
+    // wave-uniform: every active lane's ray is plain
+    const bool all_plain = UNIFORM_KIND && __ballot(!ray_is_plain(o, d)) == 0ull;
     for (uint32_t i = 0; i < tab.n_prims; ++i) {
         Geom g = load_geom(tab.geom, i);
-        LocalRay lr = to_local(g, o, d);
+        LocalRay lr;
+        if (UNIFORM_KIND && all_plain && (__builtin_amdgcn_readfirstlane(g.flags) & kGeomIdentity))
+            lr = to_local_identity(g, o, d);
+        else
+            lr = to_local(g, o, d);
         int kind = UNIFORM_KIND ? __builtin_amdgcn_readfirstlane(g.kind) : g.kind;
         float t;
         bool hit = figure_t(kind, g.param, lr, t);
@@ -190,20 +224,22 @@ RTX_DEV Hit finish_hit(const Table &tab, int idx, V3 o, V3 d, float t, bool want
 // Full intersection of one light with a world ray: distance and world normal.
 RTX_DEV bool light_intersect(const Geom &g, V3 o, V3 d, float &t, V3 &n)
 {
-    LocalRay lr = to_local(g, o, d);
+    LocalRay lr;
+    // g is wave-uniform here (the light loop index is)
+    if ((__builtin_amdgcn_readfirstlane(g.flags) & kGeomIdentity) && __ballot(!ray_is_plain(o, d)) == 0ull)
+        lr = to_local_identity(g, o, d);
+    else
+        lr = to_local(g, o, d);
     if (!figure_t(g.kind, g.param, lr, t)) return false;
     n = world_normal(g, figure_normal(g.kind, g.param, lr, t), d);
     return true;
 }
 // src/objects/sample.rs:19-22 over :53-57 (box) and :66-74 (ellipsoid)
-RTX_DEV float light_area_pdf(const Geom &g, V3 point)
+RTX_DEV float light_area_pdf(const Geom &g, float box_area_pdf, V3 point)
 {
+    // a box's pdf does not depend on the point: 1 / (8 (ab + bc + ac)), computed at upload
+    if (g.kind == kBox) return box_area_pdf;
     V3 q = rotate_inv(g.rot, point - g.pos);
-    if (g.kind == kBox) {
-        float a = g.param.x, b = g.param.y, c = g.param.z;
-        float area = 8.0f * ((a * b + b * c) + a * c);
-        return 1.0f / area;
-    }
     V3 n = cdiv(q, g.param);
     n = cmul(n, n);
     V3 r = cmul(g.param, g.param);
@@ -211,12 +247,12 @@ RTX_DEV float light_area_pdf(const Geom &g, V3 point)
     return 1.0f / (4.0f * kPi * __builtin_sqrtf(denom));
 }
 // src/random.rs:112-128
-RTX_DEV float intersection_pdf(const Geom &g, V3 o, V3 d, float t, V3 n, V3 initial_point)
+RTX_DEV float intersection_pdf(const Geom &g, float box_area_pdf, V3 o, V3 d, float t, V3 n, V3 initial_point)
 {
     V3 obj_point = o + d * t;
     float dist = len2(initial_point - obj_point);
     float cosv = fabsf(dot(d, n));
-    float pdf = light_area_pdf(g, obj_point) * dist / cosv;
+    float pdf = light_area_pdf(g, box_area_pdf, obj_point) * dist / cosv;
     return finite_f(pdf) ? pdf : 0.0f;
 }
 // src/random.rs:83-109: every light is intersected by the ray from p along d, and again
@@ -228,7 +264,9 @@ RTX_DEV float light_pdf(const Table &tab, V3 p, V3 dir, Counters<STATS> &cnt)
     V3 d = normalize(dir);
     float pdf = 0.0f;
     for (uint32_t li = 0; li < tab.n_lights; ++li) {
-        Geom g = load_geom(tab.geom, (uint32_t)tab.lights[li]);
+        const uint32_t lidx = (uint32_t)tab.lights[li];
+        Geom g = load_geom(tab.geom, lidx);
+        const float box_area_pdf = tab.mat[3 * lidx + 2].w;
         cnt.template add<C_LTEST_ELLIPSOID>(g.kind == kEllipsoid);
         cnt.template add<C_LTEST_BOX>(g.kind == kBox);
         float t1, t2;
@@ -237,7 +275,7 @@ RTX_DEV float light_pdf(const Table &tab, V3 p, V3 dir, Counters<STATS> &cnt)
             cnt.template add<C_LPDF_0>();
             continue;
         }
-        pdf += intersection_pdf(g, p, d, t1, n1, p);
+        pdf += intersection_pdf(g, box_area_pdf, p, d, t1, n1, p);
         // Ray::new_shifted normalises the (already unit) direction once more
         V3 d2 = normalize(d);
         V3 o2 = (p + d * t1) + d2 * kRayEps;
@@ -247,10 +285,11 @@ RTX_DEV float light_pdf(const Table &tab, V3 p, V3 dir, Counters<STATS> &cnt)
             cnt.template add<C_LPDF_1>();
             continue;
         }
-        pdf += intersection_pdf(g, o2, d2, t2, n2, p);
+        pdf += intersection_pdf(g, box_area_pdf, o2, d2, t2, n2, p);
         cnt.template add<C_LPDF_2>();
     }
-    return pdf / (float)tab.n_lights;
+    // x / 1.0f is x: the division is skipped for a single light
+    return tab.n_lights == 1 ? pdf : pdf / (float)tab.n_lights;
 }
 // src/random.rs:143-161
 template <bool STATS>
@@ -372,7 +411,7 @@ RTX_DEV void camera_ray(const RenderParams &P, uint32_t i, uint32_t j, float du,
 // the scatter at the last allowed depth multiplies a zero and is skipped.
 RTX_DEV bool surface_emission(const RenderParams &P, const Table &tab, Path &p, int idx)
 {
-    float4 m1 = tab.mat[2 * idx + 1];
+    float4 m1 = tab.mat[3 * idx + 1];
     p.L = p.L + cmul(p.T, v3(m1.x, m1.y, m1.z));
     return p.depth + 1 >= P.ray_depth;
 }
@@ -385,7 +424,7 @@ template <bool STATS>
 RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, float t, int material,
                     uint32_t pixel, uint32_t sample, Counters<STATS> &cnt)
 {
-    float4 m0 = tab.mat[2 * idx + 0], m1 = tab.mat[2 * idx + 1];
+    float4 m0 = tab.mat[3 * idx + 0], m1 = tab.mat[3 * idx + 1];
     V3 color = v3(m0.x, m0.y, m0.z);
 
     Hit h = finish_hit(tab, idx, p.o, p.d, t, material == kDielectric);
@@ -393,7 +432,8 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
     V3 n = h.n;
 
     if (material == kDiffuse) {
-        V3 color_obj = color / kPi;
+        float4 m2 = tab.mat[3 * idx + 2];
+        V3 color_obj = v3(m2.x, m2.y, m2.z);  // color / pi, divided at upload
         uint4 w = draw_block(P, pixel, sample, p.depth + 1);
         V3 new_dir;
         bool pick_cosine = tab.n_lights == 0 || (w.x >> 31) == 0u;
@@ -456,7 +496,7 @@ RTX_DEV bool scatter(const RenderParams &P, const Table &tab, Path &p, int idx, 
                      uint32_t pixel, uint32_t sample, Counters<STATS> &cnt)
 {
     if (surface_emission(P, tab, p, idx)) return true;
-    int material = __float_as_int(tab.mat[2 * idx + 0].w);
+    int material = __float_as_int(tab.mat[3 * idx + 0].w);
     return bounce<STATS>(P, tab, p, idx, t, material, pixel, sample, cnt);
 }
 

@@ -35,7 +35,7 @@ RTX_DEV Table wf_table(const RenderParams &P, bool lds)
     t.n_prims = P.n_prims;
     t.n_lights = P.n_lights;
     if (lds) {
-        const uint32_t ng = 3u * P.n_prims, nm = 2u * P.n_prims;
+        const uint32_t ng = 3u * P.n_prims, nm = 3u * P.n_prims;
         for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) rtx_smem[i] = P.geom[i];
         for (uint32_t i = threadIdx.x; i < nm; i += blockDim.x) rtx_smem[ng + i] = P.mat[i];
         int32_t *sl = reinterpret_cast<int32_t *>(rtx_smem + ng + nm);
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256) k_wf_extend(const RenderParams P, const W
                 done = true;
             } else {
                 if constexpr (STATS) {
-                    int kind = __float_as_int(tab.geom[3 * idx + 1].w);
+                    int kind = __float_as_int(tab.geom[3 * idx + 1].w) & 0xff;
                     cnt.template add<C_HIT_PLANE>(kind == kPlane);
                     cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
                     cnt.template add<C_HIT_BOX>(kind == kBox);
@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(256) k_wf_extend(const RenderParams P, const W
                 wf_store_rad(S, px, p);
                 S.hit_t[px] = t;
                 S.hit_idx[px] = idx;
-                material = __float_as_int(tab.mat[2 * idx + 0].w);
+                material = __float_as_int(tab.mat[3 * idx + 0].w);
             }
         }
         wf_push(S, Q_FRESH0 + nxt, refresh, px);
