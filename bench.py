@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--spp", type=int, default=None)
     ap.add_argument("--size", type=int, nargs=2, default=None)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--depth", type=int, default=None, help="override RAY_DEPTH (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
     args = ap.parse_args()
@@ -105,6 +106,9 @@ def main():
 
     name = args.workload or ("c2" if world == 1 else "c4")
     scene, desc = build_workload(name, args.spp, args.size)
+    if args.depth is not None:
+        scene = scene.replace(ray_depth=args.depth)
+        desc += f" [depth overridden to {args.depth}]"
     mode = {"megakernel": _abi.MODE_MEGAKERNEL, "wavefront": _abi.MODE_WAVEFRONT}[args.mode]
     accel = {"auto": _abi.ACCEL_AUTO, "lds": _abi.ACCEL_BRUTE_LDS, "scalar": _abi.ACCEL_BRUTE_SCALAR,
              "bvh": _abi.ACCEL_BVH}[args.accel]

@@ -69,8 +69,11 @@ RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, flo
     else return closest_hit_scan<true>(tab, o, d, t);
 }
 
+#ifndef RTX_MEGAKERNEL_ATTR
+#define RTX_MEGAKERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))  // at most 128 VGPRs: 4 waves per SIMD measured fastest
+#endif
 template <int SRC, bool STATS>
-__global__ void __launch_bounds__(256) k_megakernel(const RenderParams P)
+__global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const RenderParams P)
 {
     Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
     uint32_t px, py;

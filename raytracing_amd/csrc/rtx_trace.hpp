@@ -221,17 +221,36 @@ RTX_DEV Hit finish_hit(const Table &tab, int idx, V3 o, V3 d, float t, bool want
 }
 
 // -------------------------------------------------------------------- lights
-// Full intersection of one light with a world ray: distance and world normal.
-RTX_DEV bool light_intersect(const Geom &g, V3 o, V3 d, float &t, V3 &n)
+// Intersection of one light with a world ray as the light pdf needs it: the distance and
+// |cos| between the ray and the surface normal there (src/random.rs:120).  The reference flips
+// the normal against the ray first (src/objects/geometry.rs:31-33); negating a vector negates
+// its dot product exactly, so the absolute value is taken of the unflipped one.
+// `g` is wave-uniform (the light loop index is).
+RTX_DEV bool light_intersect_cos(const Geom &g, V3 o, V3 d, float &t, float &cosv)
 {
-    LocalRay lr;
-    // g is wave-uniform here (the light loop index is)
-    if ((__builtin_amdgcn_readfirstlane(g.flags) & kGeomIdentity) && __ballot(!ray_is_plain(o, d)) == 0ull)
-        lr = to_local_identity(g, o, d);
-    else
-        lr = to_local(g, o, d);
+    const bool ident = (__builtin_amdgcn_readfirstlane(g.flags) & kGeomIdentity) &&
+                       __ballot(!ray_is_plain(o, d)) == 0ull;
+    LocalRay lr = ident ? to_local_identity(g, o, d) : to_local(g, o, d);
     if (!figure_t(g.kind, g.param, lr, t)) return false;
-    n = world_normal(g, figure_normal(g.kind, g.param, lr, t), d);
+    if (ident && __builtin_amdgcn_readfirstlane(g.kind) == kBox) {
+        // Axis-aligned box: the local normal is v * e_k (k = first axis of largest |.|, the
+        // other two components are +0).  The identity rotation returns it unchanged, and
+        // normalising it gives exactly +-e_k: sqrt(fl(v*v)) = |v| in binary floating point when
+        // v*v neither overflows nor underflows, and v / |v| = +-1.  Hence |n . d| = |d_k|.
+        V3 q = cdiv(lr.o + lr.d * t, g.param);
+        float ax = fabsf(q.x), ay = fabsf(q.y), az = fabsf(q.z);
+        int k = 0;
+        float vm = ax;
+        if (ay > vm) { vm = ay; k = 1; }
+        if (az > vm) { vm = az; k = 2; }
+        const bool tame = vm > 1e-18f && vm < 1e18f;
+        if (__ballot(!tame) == 0ull) {
+            cosv = fabsf(k == 0 ? d.x : (k == 1 ? d.y : d.z));
+            return true;
+        }
+    }
+    V3 n = normalize(rotate(g.rot, figure_normal(g.kind, g.param, lr, t)));
+    cosv = fabsf(dot(n, d));
     return true;
 }
 // src/objects/sample.rs:19-22 over :53-57 (box) and :66-74 (ellipsoid)
@@ -247,11 +266,10 @@ RTX_DEV float light_area_pdf(const Geom &g, float box_area_pdf, V3 point)
     return 1.0f / (4.0f * kPi * __builtin_sqrtf(denom));
 }
 // src/random.rs:112-128
-RTX_DEV float intersection_pdf(const Geom &g, float box_area_pdf, V3 o, V3 d, float t, V3 n, V3 initial_point)
+RTX_DEV float intersection_pdf(const Geom &g, float box_area_pdf, V3 o, V3 d, float t, float cosv, V3 initial_point)
 {
     V3 obj_point = o + d * t;
     float dist = len2(initial_point - obj_point);
-    float cosv = fabsf(dot(d, n));
     float pdf = light_area_pdf(g, box_area_pdf, obj_point) * dist / cosv;
     return finite_f(pdf) ? pdf : 0.0f;
 }
@@ -269,23 +287,22 @@ RTX_DEV float light_pdf(const Table &tab, V3 p, V3 dir, Counters<STATS> &cnt)
         const float box_area_pdf = tab.mat[3 * lidx + 2].w;
         cnt.template add<C_LTEST_ELLIPSOID>(g.kind == kEllipsoid);
         cnt.template add<C_LTEST_BOX>(g.kind == kBox);
-        float t1, t2;
-        V3 n1, n2;
-        if (!light_intersect(g, p, d, t1, n1)) {
+        float t1, t2, c1, c2;
+        if (!light_intersect_cos(g, p, d, t1, c1)) {
             cnt.template add<C_LPDF_0>();
             continue;
         }
-        pdf += intersection_pdf(g, box_area_pdf, p, d, t1, n1, p);
+        pdf += intersection_pdf(g, box_area_pdf, p, d, t1, c1, p);
         // Ray::new_shifted normalises the (already unit) direction once more
         V3 d2 = normalize(d);
         V3 o2 = (p + d * t1) + d2 * kRayEps;
         cnt.template add<C_LTEST_ELLIPSOID>(g.kind == kEllipsoid);
         cnt.template add<C_LTEST_BOX>(g.kind == kBox);
-        if (!light_intersect(g, o2, d2, t2, n2)) {
+        if (!light_intersect_cos(g, o2, d2, t2, c2)) {
             cnt.template add<C_LPDF_1>();
             continue;
         }
-        pdf += intersection_pdf(g, box_area_pdf, o2, d2, t2, n2, p);
+        pdf += intersection_pdf(g, box_area_pdf, o2, d2, t2, c2, p);
         cnt.template add<C_LPDF_2>();
     }
     // x / 1.0f is x: the division is skipped for a single light
@@ -297,6 +314,9 @@ RTX_DEV float mis_pdf(const Table &tab, V3 p, V3 n, V3 d, Counters<STATS> &cnt)
 {
     float a = tab.n_lights == 0 ? 1.0f : 0.5f;
     float cos_pdf = rmax(dot(n, d), 0.0f) / kPi;
+#if defined(RTX_ABLATE) && RTX_ABLATE == 1
+    return cos_pdf * a + (p.x * 1e-9f + 0.05f) * (1.0f - a);
+#endif
     return cos_pdf * a + light_pdf<STATS>(tab, p, d, cnt) * (1.0f - a);
 }
 
@@ -389,6 +409,13 @@ struct Path {
 RTX_DEV uint4 draw_block(const RenderParams &P, uint32_t pixel, uint32_t sample, uint32_t slot)
 {
     if (P.rng_const) return make_uint4(P.const_words[0], P.const_words[1], P.const_words[2], P.const_words[3]);
+#if defined(RTX_ABLATE) && RTX_ABLATE == 4
+    {
+        uint32_t h = (pixel * 0x9E3779B9u) ^ (sample * 0x85EBCA6Bu) ^ (slot * 0xC2B2AE35u) ^ P.seed_lo;
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+        return make_uint4(h, h * 0x297A2D39u, h * 0x85EBCA6Bu + 0x1234567u, h * 0xC2B2AE35u + 0x7654321u);
+    }
+#endif
     return philox4x32_10(pixel, sample, slot, 0u, P.seed_lo, P.seed_hi);
 }
 
@@ -427,7 +454,13 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
     float4 m0 = tab.mat[3 * idx + 0], m1 = tab.mat[3 * idx + 1];
     V3 color = v3(m0.x, m0.y, m0.z);
 
+#if defined(RTX_ABLATE) && RTX_ABLATE == 3
+    Hit h;
+    h.n = -p.d;
+    h.inside = false;
+#else
     Hit h = finish_hit(tab, idx, p.o, p.d, t, material == kDielectric);
+#endif
     V3 point = p.o + p.d * t;
     V3 n = h.n;
 
@@ -437,10 +470,19 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
         uint4 w = draw_block(P, pixel, sample, p.depth + 1);
         V3 new_dir;
         bool pick_cosine = tab.n_lights == 0 || (w.x >> 31) == 0u;
+#if defined(RTX_ABLATE) && RTX_ABLATE == 2
+        new_dir = n + v3(u24(w.y) - 0.5f, u24(w.z) - 0.5f, u24(w.w) - 0.5f);
+        if (false) {
+#else
         if (pick_cosine) {
+#endif
             cnt.template add<C_COSINE>();
             new_dir = cosine_sample(n, w.y, w.z);
+#if defined(RTX_ABLATE) && RTX_ABLATE == 2
+        } else if (false) {
+#else
         } else {
+#endif
             uint32_t li = __umulhi(w.x << 2, tab.n_lights);
             Geom lg = load_geom(tab.geom, (uint32_t)tab.lights[li]);
             cnt.template add<C_LSAMPLE_ELLIPSOID>(lg.kind == kEllipsoid);

@@ -15,7 +15,8 @@ from . import _abi
 from .scene import Scene
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx.so")
+# RTX_LIB selects another build of the same library (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("RTX_LIB") or os.path.join(_HERE, "librtx.so")
 
 # every entry point include/rtx.h declares: (name, restype, argtypes)
 _FP = C.POINTER(C.c_float)
