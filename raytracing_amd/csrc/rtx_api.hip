@@ -72,9 +72,8 @@ struct rtx_ctx {
     // scratch owned by the context
     float *d_image = nullptr;
     size_t d_image_floats = 0;
-    void *d_wavefront = nullptr;  // path state + queues of the wavefront variant
+    void *d_wavefront = nullptr;  // path state of the wavefront variant
     size_t d_wavefront_bytes = 0;
-    uint32_t wavefront_iterations = 0;
     unsigned long long *d_stats = nullptr;
     rtx_stats stats{};
     bool stats_valid = false;
@@ -378,8 +377,7 @@ int rtx_render_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count,
     if (stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, rtx::C_COUNT * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(c->ev_start, stream));
     if (c->opts.mode == RTX_MODE_WAVEFRONT) {
-        const uint32_t n_pixels = P.width * P.height;
-        const size_t need = rtx::wavefront_state_bytes(n_pixels);
+        const size_t need = rtx::wavefront_state_bytes(P.width, P.height);
         if (c->d_wavefront_bytes < need) {
             if (c->d_wavefront) (void)hipFree(c->d_wavefront);
             c->d_wavefront = nullptr;
@@ -388,8 +386,8 @@ int rtx_render_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count,
             c->d_wavefront_bytes = need;
         }
         rtx::WfState S;
-        rtx::wavefront_bind_state(c->d_wavefront, n_pixels, S);
-        HIP_TRY(rtx::launch_wavefront(P, S, c->src, stats, stream, &c->wavefront_iterations));
+        rtx::wavefront_bind_state(c->d_wavefront, P.width, P.height, S);
+        HIP_TRY(rtx::launch_wavefront(P, S, c->src, stats, stream));
     } else {
         HIP_TRY(rtx::launch_megakernel(P, c->src, stats, stream));
     }

@@ -42,10 +42,11 @@ RTX_DEV bool slab_test(V3 lo, V3 hi, V3 o, V3 inv, float t_limit, float &t_near)
     return tn <= tf && !(tn > t_limit);
 }
 
-template <bool STATS>
+// BLOCK = threads per workgroup of the calling kernel (the stack array is sized for it)
+template <bool STATS, int BLOCK = 256>
 RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, float &best_t, Counters<STATS> &cnt)
 {
-    __shared__ int32_t s_stack[kBvhStackSize * 256];
+    __shared__ int32_t s_stack[kBvhStackSize * BLOCK];
     int32_t *stack = s_stack + threadIdx.x;
 
     const float ray_length = len(d);
@@ -83,7 +84,7 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
             bool first0 = d0 <= d1;
             int near_c = first0 ? c0 : c1, far_c = first0 ? c1 : c0;
             if (sp < kBvhStackSize) {
-                stack[sp * 256] = far_c;
+                stack[sp * BLOCK] = far_c;
                 sp++;
             }
             node = near_c;
@@ -94,7 +95,7 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
         } else {
             if (sp == 0) break;
             sp--;
-            node = stack[sp * 256];
+            node = stack[sp * BLOCK];
         }
     }
     return best;

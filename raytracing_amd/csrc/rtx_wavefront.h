@@ -1,10 +1,11 @@
-// rtx_wavefront.h -- path state and queues of the wavefront variant (see rtx_wavefront.hip).
+// rtx_wavefront.h -- path state of the wavefront variant (see rtx_wavefront.hip).
 #pragma once
 #include "rtx_device.h"
 
 namespace rtx {
 
-// Structure-of-arrays path state, one entry per pixel, plus the index queues.
+// Structure-of-arrays path state in device memory, one entry per slot (workgroup * 4096 +
+// workgroup-local pixel number).
 struct WfState {
     float *ray[6];     // origin xyz, direction xyz
     float *thr[3];     // throughput
@@ -13,14 +14,11 @@ struct WfState {
     uint32_t *sample;  // global index of the sample the pixel is working on
     float *hit_t;      // closest hit of the current segment
     int32_t *hit_idx;
-    uint32_t *queue[7];
-    uint32_t *counts;  // queue lengths [7] + live-path count
 };
 
-size_t wavefront_state_bytes(uint32_t n_pixels);
-void wavefront_bind_state(void *block, uint32_t n_pixels, WfState &S);
-// Renders samples [P.sample_first, +P.sample_count) into P.out_sum; blocks until done.
-hipError_t launch_wavefront(const RenderParams &P, const WfState &S, int src, bool stats, hipStream_t stream,
-                            uint32_t *iterations_out);
+size_t wavefront_state_bytes(uint32_t width, uint32_t height);
+void wavefront_bind_state(void *block, uint32_t width, uint32_t height, WfState &S);
+// Renders samples [P.sample_first, +P.sample_count) into P.out_sum: one asynchronous launch.
+hipError_t launch_wavefront(const RenderParams &P, const WfState &S, int src, bool stats, hipStream_t stream);
 
 }  // namespace rtx

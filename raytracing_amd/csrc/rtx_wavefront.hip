@@ -1,59 +1,49 @@
-// rtx_wavefront.hip -- wavefront variant of the trace loop (gfx950).
+// rtx_wavefront.hip -- wavefront variant of the trace loop (gfx950): one launch, workgroup-
+// local queues in LDS, path state in HBM.
 //
 // The same per-pixel computation as k_megakernel, cut into stages that each run with
-// (almost) every lane busy.  Path state lives in HBM as structure-of-arrays indexed by
-// pixel: a pixel has at most one path in flight, so its samples are still accumulated in
-// sample order and the result is bit-identical to the megakernel's.
+// (almost) every lane busy.  A workgroup of 512 threads owns 64 tiles of 8x8 pixels (4096
+// pixels) from start to finish, so no path ever crosses a workgroup: queue counters and the
+// queues themselves live in LDS, there are no global atomics, no inter-kernel hand-offs and
+// no host round trips.  A pixel has at most one path in flight, so its samples are still
+// accumulated in sample order and the image is bit-identical to the megakernel's.
 //
-// Queues hold pixel indices.  One iteration advances every live path by one segment:
-//   prepare   reset the counters this iteration fills
+// Path state is structure-of-arrays in HBM (64 B per pixel), indexed by SLOT = workgroup *
+// 4096 + workgroup-local pixel number, so the lanes of a wave -- which hold consecutive queue
+// entries, i.e. nearly consecutive local numbers -- read and write contiguous addresses; only
+// the radiance sum (the output buffer) is indexed by pixel.  Queues hold 16-bit local numbers.
+// One iteration of the in-kernel loop advances every live path of the workgroup by one
+// segment:
 //   generate  fresh queue  -> primary ray of the pixel's next sample -> active queue
-//   extend    active queue -> closest hit; miss and depth cut finish the path here
-//                             (-> next fresh queue); others -> queue of the hit's material
-//   shade<M>  queue M      -> one material per launch: scatter; continuing paths -> next
+//   extend    active queue -> closest hit; a miss or the depth cut finishes the path here
+//                             (-> next fresh queue); others -> the queue of the hit's material
+//   shade<M>  queue M      -> one material at a time: scatter; continuing paths -> next
 //                             active queue, rejected diffuse samples -> next fresh queue
-// Appending to a queue is a wave64 compaction: ballot of the predicate, prefix popcount
-// below the lane, ONE atomicAdd per wave for the base offset.
-// Stage kernels run on a fixed grid and stride over their queue in wave-sized chunks, so
-// the host never needs a queue length to launch them; it reads the live-path count back
-// once per batch of iterations to know when to stop.
+// Appending to a queue is a wave64 compaction: ballot of the predicate, count of set bits
+// below the lane (v_mbcnt), ONE LDS atomic per wave for the base offset.
 #include "rtx_bvh_traverse.hpp"
 #include "rtx_trace.hpp"
 #include "rtx_wavefront.h"
 
 namespace rtx {
 
-extern __shared__ float4 rtx_smem[];
-
 namespace {
+
+constexpr uint32_t kWfThreads = 512;
+constexpr uint32_t kWfTilesPerGroup = 64;                       // 8x8 pixel tiles
+constexpr uint32_t kWfPixelsPerGroup = kWfTilesPerGroup * 64u;  // 4096: fits 16-bit queue entries
 
 enum : int { Q_ACTIVE0 = 0, Q_ACTIVE1, Q_FRESH0, Q_FRESH1, Q_DIFFUSE, Q_METALLIC, Q_DIELECTRIC, Q_COUNT };
 
-RTX_DEV Table wf_table(const RenderParams &P, bool lds)
-{
-    Table t;
-    t.n_prims = P.n_prims;
-    t.n_lights = P.n_lights;
-    if (lds) {
-        const uint32_t ng = 3u * P.n_prims, nm = 3u * P.n_prims;
-        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) rtx_smem[i] = P.geom[i];
-        for (uint32_t i = threadIdx.x; i < nm; i += blockDim.x) rtx_smem[ng + i] = P.mat[i];
-        int32_t *sl = reinterpret_cast<int32_t *>(rtx_smem + ng + nm);
-        for (uint32_t i = threadIdx.x; i < P.n_lights; i += blockDim.x) sl[i] = P.lights[i];
-        __syncthreads();
-        t.geom = rtx_smem;
-        t.mat = rtx_smem + ng;
-        t.lights = sl;
-    } else {
-        t.geom = P.geom;
-        t.mat = P.mat;
-        t.lights = P.lights;
-    }
-    return t;
-}
+struct WfLds {
+    uint16_t queue[Q_COUNT][kWfPixelsPerGroup];
+    uint32_t count[Q_COUNT];
+};
 
-// wave64 compaction: lanes with `pred` append `value` to queue q
-RTX_DEV void wf_push(const WfState &S, int q, bool pred, uint32_t value)
+extern __shared__ float4 rtx_smem[];
+
+// wave64 compaction into an LDS queue: lanes with `pred` append `value`
+RTX_DEV void wf_push(WfLds &L, int q, bool pred, uint32_t value)
 {
     const unsigned long long mask = __ballot(pred);
     if (mask == 0ull) return;
@@ -61,9 +51,20 @@ RTX_DEV void wf_push(const WfState &S, int q, bool pred, uint32_t value)
     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     const int leader = __builtin_ctzll(mask);
     uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(&S.counts[q], (uint32_t)__popcll(mask));
+    if ((int)lane == leader) base = atomicAdd(&L.count[q], (uint32_t)__popcll(mask));
     base = __shfl(base, leader, 64);
-    if (pred) S.queue[q][base + below] = value;
+    if (pred) L.queue[q][base + below] = (uint16_t)value;
+}
+
+// workgroup-local pixel number -> pixel; tiles of a workgroup are consecutive in tile order
+RTX_DEV bool wf_pixel(const RenderParams &P, uint32_t local, uint32_t &px, uint32_t &py)
+{
+    const uint32_t tile = blockIdx.x * kWfTilesPerGroup + (local >> 6);
+    const uint32_t in_tile = local & 63u;
+    const uint32_t tiles_x = (P.width + 7u) >> 3;
+    px = (tile % tiles_x) * 8u + (in_tile & 7u);
+    py = (tile / tiles_x) * 8u + (in_tile >> 3);
+    return px < P.width && py < P.height;
 }
 
 RTX_DEV Path wf_load_path(const WfState &S, uint32_t px)
@@ -89,21 +90,199 @@ RTX_DEV void wf_store_rad(const WfState &S, uint32_t px, const Path &p)
 {
     S.rad[0][px] = p.L.x; S.rad[1][px] = p.L.y; S.rad[2][px] = p.L.z;
 }
-// the path of pixel px is complete: add it to the pixel's sum, move to the next sample
-RTX_DEV bool wf_finish_path(const RenderParams &P, const WfState &S, uint32_t px, V3 L)
+// the path of pixel `pixel` is complete: add it to the pixel's sum, move to the next sample
+RTX_DEV bool wf_finish_path(const RenderParams &P, const WfState &S, uint32_t slot, uint32_t pixel, V3 L)
 {
-    float *out = P.out_sum + 3ull * px;
+    float *out = P.out_sum + 3ull * pixel;
     out[0] = out[0] + L.x;
     out[1] = out[1] + L.y;
     out[2] = out[2] + L.z;
-    uint32_t s = S.sample[px] + 1u;
-    S.sample[px] = s;
+    uint32_t s = S.sample[slot] + 1u;
+    S.sample[slot] = s;
     return s < P.sample_first + P.sample_count;  // more samples to do
 }
 
-template <bool STATS>
-RTX_DEV void wf_flush(const RenderParams &P, const Counters<STATS> &cnt)
+// one material's queue: scatter (src/trace.rs:25-68 for that material)
+template <int MATERIAL, bool STATS>
+RTX_DEV void wf_shade(const RenderParams &P, const WfState &S, WfLds &L, const Table &tab, uint32_t nxt,
+                      Counters<STATS> &cnt)
 {
+    const uint32_t count = L.count[Q_DIFFUSE + MATERIAL];
+    for (uint32_t base = 0; base < count; base += kWfThreads) {
+        const uint32_t i = base + threadIdx.x;
+        const bool valid = i < count;
+        uint32_t local = 0;
+        bool go_on = false, refresh = false;
+        if (valid) {
+            local = L.queue[Q_DIFFUSE + MATERIAL][i];
+            uint32_t px, py;
+            wf_pixel(P, local, px, py);
+            const uint32_t pixel = py * P.width + px;
+            const uint32_t slot = blockIdx.x * kWfPixelsPerGroup + local;
+            Path p = wf_load_path(S, slot);
+            const bool ended = bounce<STATS>(P, tab, p, S.hit_idx[slot], S.hit_t[slot], MATERIAL, pixel,
+                                             S.sample[slot], cnt);
+            if (ended) {
+                refresh = wf_finish_path(P, S, slot, pixel, p.L);
+            } else {
+                wf_store_ray(S, slot, p);
+                wf_store_thr(S, slot, p);
+                S.depth[slot] = p.depth;
+                go_on = true;
+            }
+        }
+        wf_push(L, Q_ACTIVE0 + nxt, go_on, local);
+        wf_push(L, Q_FRESH0 + nxt, refresh, local);
+    }
+}
+
+template <int SRC, bool STATS>
+__global__ void __launch_bounds__(kWfThreads) k_wavefront(const RenderParams P, const WfState S)
+{
+    // dynamic LDS: [queues + counters][object table when SRC == kSrcLds]
+    WfLds &L = *reinterpret_cast<WfLds *>(rtx_smem);
+    Table tab;
+    tab.n_prims = P.n_prims;
+    tab.n_lights = P.n_lights;
+    if constexpr (SRC == kSrcLds) {
+        float4 *tbl = rtx_smem + (sizeof(WfLds) + 15u) / 16u;
+        const uint32_t ng = 3u * P.n_prims, nm = 3u * P.n_prims;
+        for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) tbl[i] = P.geom[i];
+        for (uint32_t i = threadIdx.x; i < nm; i += blockDim.x) tbl[ng + i] = P.mat[i];
+        int32_t *sl = reinterpret_cast<int32_t *>(tbl + ng + nm);
+        for (uint32_t i = threadIdx.x; i < P.n_lights; i += blockDim.x) sl[i] = P.lights[i];
+        tab.geom = tbl;
+        tab.mat = tbl + ng;
+        tab.lights = sl;
+    } else {
+        tab.geom = P.geom;
+        tab.mat = P.mat;
+        tab.lights = P.lights;
+    }
+    if (threadIdx.x < Q_COUNT) L.count[threadIdx.x] = 0u;
+    __syncthreads();
+
+    const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
+    Counters<STATS> cnt;
+    cnt.clear();
+
+    // every pixel of the workgroup starts in the fresh queue with a zero sum
+    for (uint32_t base = 0; base < kWfPixelsPerGroup; base += kWfThreads) {
+        const uint32_t local = base + threadIdx.x;
+        uint32_t px, py;
+        const bool valid = wf_pixel(P, local, px, py);
+        if (valid) {
+            const uint32_t pixel = py * P.width + px;
+            S.sample[blockIdx.x * kWfPixelsPerGroup + local] = P.sample_first;
+            P.out_sum[3ull * pixel + 0] = 0.0f;
+            P.out_sum[3ull * pixel + 1] = 0.0f;
+            P.out_sum[3ull * pixel + 2] = 0.0f;
+        }
+        wf_push(L, Q_FRESH0, valid && P.sample_count > 0u, local);
+    }
+    __syncthreads();
+
+    for (uint32_t it = 0;; ++it) {
+        const uint32_t cur = it & 1u, nxt = cur ^ 1u;
+        if (threadIdx.x == 0) {
+            L.count[Q_ACTIVE0 + nxt] = 0u;
+            L.count[Q_FRESH0 + nxt] = 0u;
+            L.count[Q_DIFFUSE] = 0u;
+            L.count[Q_METALLIC] = 0u;
+            L.count[Q_DIELECTRIC] = 0u;
+        }
+        __syncthreads();
+
+        // ---- generate: src/main.rs:17-21
+        {
+            const uint32_t count = L.count[Q_FRESH0 + cur];
+            for (uint32_t base = 0; base < count; base += kWfThreads) {
+                const uint32_t i = base + threadIdx.x;
+                const bool valid = i < count;
+                uint32_t local = 0;
+                if (valid) {
+                    local = L.queue[Q_FRESH0 + cur][i];
+                    uint32_t px, py;
+                    wf_pixel(P, local, px, py);
+                    const uint32_t pixel = py * P.width + px;
+                    const uint32_t slot = blockIdx.x * kWfPixelsPerGroup + local;
+                    uint4 w = draw_block(P, pixel, S.sample[slot], 0u);
+                    Path p;
+                    camera_ray(P, px, P.height - 1u - py, u24(w.x), u24(w.y), p.o, p.d);
+                    p.T = v3(1.0f, 1.0f, 1.0f);
+                    p.L = v3(0.0f, 0.0f, 0.0f);
+                    wf_store_ray(S, slot, p);
+                    wf_store_thr(S, slot, p);
+                    wf_store_rad(S, slot, p);
+                    S.depth[slot] = 0u;
+                    cnt.template add<C_SAMPLES>();
+                }
+                wf_push(L, Q_ACTIVE0 + cur, valid, local);
+            }
+        }
+        __syncthreads();
+
+        // ---- extend: src/trace.rs:12-23
+        {
+            const uint32_t count = L.count[Q_ACTIVE0 + cur];
+            for (uint32_t base = 0; base < count; base += kWfThreads) {
+                const uint32_t i = base + threadIdx.x;
+                const bool valid = i < count;
+                uint32_t local = 0;
+                int material = -1;
+                bool refresh = false;
+                if (valid) {
+                    local = L.queue[Q_ACTIVE0 + cur][i];
+                    uint32_t px, py;
+                    wf_pixel(P, local, px, py);
+                    const uint32_t pixel = py * P.width + px;
+                    const uint32_t slot = blockIdx.x * kWfPixelsPerGroup + local;
+                    Path p = wf_load_path(S, slot);
+                    cnt.template add<C_RAYS>();
+                    float t;
+                    int idx;
+                    if constexpr (SRC == kSrcBvh) idx = closest_hit_bvh<STATS, (int)kWfThreads>(P.bvh, tab, p.o, p.d, t, cnt);
+                    else idx = closest_hit_scan<true>(tab, p.o, p.d, t);
+                    bool done;
+                    if (idx < 0) {
+                        p.L = p.L + cmul(p.T, bg);
+                        done = true;
+                    } else {
+                        if constexpr (STATS) {
+                            int kind = __float_as_int(tab.geom[3 * idx + 1].w) & 0xff;
+                            cnt.template add<C_HIT_PLANE>(kind == kPlane);
+                            cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
+                            cnt.template add<C_HIT_BOX>(kind == kBox);
+                        }
+                        done = surface_emission(P, tab, p, idx);
+                    }
+                    if (done) {
+                        refresh = wf_finish_path(P, S, slot, pixel, p.L);
+                    } else {
+                        wf_store_rad(S, slot, p);
+                        S.hit_t[slot] = t;
+                        S.hit_idx[slot] = idx;
+                        material = __float_as_int(tab.mat[3 * idx + 0].w);
+                    }
+                }
+                wf_push(L, Q_FRESH0 + nxt, refresh, local);
+                wf_push(L, Q_DIFFUSE, material == kDiffuse, local);
+                wf_push(L, Q_METALLIC, material == kMetallic, local);
+                wf_push(L, Q_DIELECTRIC, material == kDielectric, local);
+            }
+        }
+        __syncthreads();
+
+        // ---- shade, one material at a time
+        wf_shade<kDiffuse, STATS>(P, S, L, tab, nxt, cnt);
+        wf_shade<kMetallic, STATS>(P, S, L, tab, nxt, cnt);
+        wf_shade<kDielectric, STATS>(P, S, L, tab, nxt, cnt);
+        __syncthreads();
+
+        if (L.count[Q_ACTIVE0 + nxt] + L.count[Q_FRESH0 + nxt] == 0u) break;
+        __syncthreads();  // the counters are reset at the top of the next iteration
+    }
+
     if constexpr (STATS) {
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i)
@@ -111,183 +290,26 @@ RTX_DEV void wf_flush(const RenderParams &P, const Counters<STATS> &cnt)
     }
 }
 
-#define WF_FOR_EACH_CHUNK(count_expr)                                                          \
-    const uint32_t wf_count = (count_expr);                                                    \
-    const uint32_t wf_lane = threadIdx.x & 63u;                                                \
-    const uint32_t wf_wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;                     \
-    const uint32_t wf_nwaves = (gridDim.x * blockDim.x) >> 6;                                  \
-    for (uint32_t wf_base = wf_wave * 64u; wf_base < wf_count; wf_base += wf_nwaves * 64u)
-
-__global__ void __launch_bounds__(256) k_wf_init(const RenderParams P, const WfState S)
-{
-    const uint32_t n = P.width * P.height;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        S.sample[i] = P.sample_first;
-        S.queue[Q_FRESH0][i] = i;
-        P.out_sum[3ull * i + 0] = 0.0f;
-        P.out_sum[3ull * i + 1] = 0.0f;
-        P.out_sum[3ull * i + 2] = 0.0f;
-    }
-    if (blockIdx.x == 0 && threadIdx.x < Q_COUNT)
-        S.counts[threadIdx.x] = (threadIdx.x == Q_FRESH0 && P.sample_count > 0) ? n : 0u;
-}
-
-// iteration `it`: resets the queues this iteration fills, publishes the live-path count
-__global__ void k_wf_prepare(const WfState S, uint32_t it)
-{
-    const uint32_t cur = it & 1u, nxt = cur ^ 1u;
-    if (threadIdx.x == 0) {
-        S.counts[Q_ACTIVE0 + nxt] = 0u;
-        S.counts[Q_FRESH0 + nxt] = 0u;
-        S.counts[Q_DIFFUSE] = 0u;
-        S.counts[Q_METALLIC] = 0u;
-        S.counts[Q_DIELECTRIC] = 0u;
-        S.counts[Q_COUNT] = S.counts[Q_ACTIVE0 + cur] + S.counts[Q_FRESH0 + cur];  // live paths
-    }
-}
-
-template <bool STATS>
-__global__ void __launch_bounds__(256) k_wf_generate(const RenderParams P, const WfState S, uint32_t it)
-{
-    const uint32_t cur = it & 1u;
-    Counters<STATS> cnt;
-    cnt.clear();
-    WF_FOR_EACH_CHUNK(S.counts[Q_FRESH0 + cur])
-    {
-        const uint32_t i = wf_base + wf_lane;
-        const bool valid = i < wf_count;
-        uint32_t px = 0;
-        if (valid) {
-            px = S.queue[Q_FRESH0 + cur][i];
-            const uint32_t pi = px % P.width, py = px / P.width;
-            const uint32_t s = S.sample[px];
-            uint4 w = draw_block(P, px, s, 0u);
-            Path p;
-            camera_ray(P, pi, P.height - 1u - py, u24(w.x), u24(w.y), p.o, p.d);
-            p.T = v3(1.0f, 1.0f, 1.0f);
-            p.L = v3(0.0f, 0.0f, 0.0f);
-            wf_store_ray(S, px, p);
-            wf_store_thr(S, px, p);
-            wf_store_rad(S, px, p);
-            S.depth[px] = 0u;
-            cnt.template add<C_SAMPLES>();
-        }
-        wf_push(S, Q_ACTIVE0 + cur, valid, px);
-    }
-    wf_flush<STATS>(P, cnt);
-}
-
-template <int SRC, bool STATS>
-__global__ void __launch_bounds__(256) k_wf_extend(const RenderParams P, const WfState S, uint32_t it)
-{
-    Table tab = wf_table(P, SRC == kSrcLds);
-    const uint32_t cur = it & 1u, nxt = cur ^ 1u;
-    const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
-    Counters<STATS> cnt;
-    cnt.clear();
-    WF_FOR_EACH_CHUNK(S.counts[Q_ACTIVE0 + cur])
-    {
-        const uint32_t i = wf_base + wf_lane;
-        const bool valid = i < wf_count;
-        uint32_t px = 0;
-        int material = -1;
-        bool refresh = false;
-        if (valid) {
-            px = S.queue[Q_ACTIVE0 + cur][i];
-            Path p = wf_load_path(S, px);
-            cnt.template add<C_RAYS>();
-            float t;
-            int idx;
-            if constexpr (SRC == kSrcBvh) idx = closest_hit_bvh<STATS>(P.bvh, tab, p.o, p.d, t, cnt);
-            else idx = closest_hit_scan<true>(tab, p.o, p.d, t);
-            bool done;
-            if (idx < 0) {
-                p.L = p.L + cmul(p.T, bg);
-                done = true;
-            } else {
-                if constexpr (STATS) {
-                    int kind = __float_as_int(tab.geom[3 * idx + 1].w) & 0xff;
-                    cnt.template add<C_HIT_PLANE>(kind == kPlane);
-                    cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
-                    cnt.template add<C_HIT_BOX>(kind == kBox);
-                }
-                done = surface_emission(P, tab, p, idx);
-            }
-            if (done) {
-                refresh = wf_finish_path(P, S, px, p.L);
-            } else {
-                wf_store_rad(S, px, p);
-                S.hit_t[px] = t;
-                S.hit_idx[px] = idx;
-                material = __float_as_int(tab.mat[3 * idx + 0].w);
-            }
-        }
-        wf_push(S, Q_FRESH0 + nxt, refresh, px);
-        wf_push(S, Q_DIFFUSE, material == kDiffuse, px);
-        wf_push(S, Q_METALLIC, material == kMetallic, px);
-        wf_push(S, Q_DIELECTRIC, material == kDielectric, px);
-    }
-    wf_flush<STATS>(P, cnt);
-}
-
-template <int SRC, int MATERIAL, bool STATS>
-__global__ void __launch_bounds__(256) k_wf_shade(const RenderParams P, const WfState S, uint32_t it)
-{
-    Table tab = wf_table(P, SRC == kSrcLds);
-    const uint32_t nxt = (it & 1u) ^ 1u;
-    Counters<STATS> cnt;
-    cnt.clear();
-    WF_FOR_EACH_CHUNK(S.counts[Q_DIFFUSE + MATERIAL])
-    {
-        const uint32_t i = wf_base + wf_lane;
-        const bool valid = i < wf_count;
-        uint32_t px = 0;
-        bool go_on = false, refresh = false;
-        if (valid) {
-            px = S.queue[Q_DIFFUSE + MATERIAL][i];
-            Path p = wf_load_path(S, px);
-            const bool ended = bounce<STATS>(P, tab, p, S.hit_idx[px], S.hit_t[px], MATERIAL, px, S.sample[px], cnt);
-            if (ended) {
-                refresh = wf_finish_path(P, S, px, p.L);
-            } else {
-                wf_store_ray(S, px, p);
-                wf_store_thr(S, px, p);
-                S.depth[px] = p.depth;
-                go_on = true;
-            }
-        }
-        wf_push(S, Q_ACTIVE0 + nxt, go_on, px);
-        wf_push(S, Q_FRESH0 + nxt, refresh, px);
-    }
-    wf_flush<STATS>(P, cnt);
-}
-
-template <int SRC, bool STATS>
-hipError_t run_iteration(const RenderParams &P, const WfState &S, uint32_t it, dim3 grid, size_t lds, hipStream_t st)
-{
-    const dim3 block(256);
-    hipLaunchKernelGGL(k_wf_prepare, dim3(1), dim3(64), 0, st, S, it);
-    hipLaunchKernelGGL((k_wf_generate<STATS>), grid, block, 0, st, P, S, it);
-    hipLaunchKernelGGL((k_wf_extend<SRC, STATS>), grid, block, lds, st, P, S, it);
-    hipLaunchKernelGGL((k_wf_shade<SRC, kDiffuse, STATS>), grid, block, lds, st, P, S, it);
-    hipLaunchKernelGGL((k_wf_shade<SRC, kMetallic, STATS>), grid, block, lds, st, P, S, it);
-    hipLaunchKernelGGL((k_wf_shade<SRC, kDielectric, STATS>), grid, block, lds, st, P, S, it);
-    return hipGetLastError();
-}
-
 }  // namespace
 
-size_t wavefront_state_bytes(uint32_t n_pixels)
+static uint32_t wavefront_slots(uint32_t width, uint32_t height)
 {
-    // 12 float arrays + depth + sample + hit_t + hit_idx + Q_COUNT queues, then the counters
-    return (size_t)n_pixels * 4u * (12u + 4u + (size_t)Q_COUNT) + 256u;
+    const uint32_t tiles = ((width + 7u) / 8u) * ((height + 7u) / 8u);
+    return (tiles + kWfTilesPerGroup - 1u) / kWfTilesPerGroup * kWfPixelsPerGroup;
 }
 
-void wavefront_bind_state(void *block, uint32_t n_pixels, WfState &S)
+size_t wavefront_state_bytes(uint32_t width, uint32_t height)
 {
+    // 12 float arrays + depth + sample + hit_t + hit_idx, one entry per slot
+    return (size_t)wavefront_slots(width, height) * 4u * 16u + 256u;
+}
+
+void wavefront_bind_state(void *block, uint32_t width, uint32_t height, WfState &S)
+{
+    const uint32_t n_slots = wavefront_slots(width, height);
     uint32_t *base = static_cast<uint32_t *>(block);
     size_t k = 0;
-    auto next = [&]() { uint32_t *p = base + k * (size_t)n_pixels; ++k; return p; };
+    auto next = [&]() { uint32_t *p = base + k * (size_t)n_slots; ++k; return p; };
     for (int i = 0; i < 6; ++i) S.ray[i] = reinterpret_cast<float *>(next());
     for (int i = 0; i < 3; ++i) S.thr[i] = reinterpret_cast<float *>(next());
     for (int i = 0; i < 3; ++i) S.rad[i] = reinterpret_cast<float *>(next());
@@ -295,50 +317,30 @@ void wavefront_bind_state(void *block, uint32_t n_pixels, WfState &S)
     S.sample = next();
     S.hit_t = reinterpret_cast<float *>(next());
     S.hit_idx = reinterpret_cast<int32_t *>(next());
-    for (int i = 0; i < Q_COUNT; ++i) S.queue[i] = next();
-    S.counts = next();
 }
 
-hipError_t launch_wavefront(const RenderParams &P, const WfState &S, int src, bool stats, hipStream_t stream,
-                            uint32_t *iterations_out)
+template <int SRC, bool STATS>
+static hipError_t launch_one(const RenderParams &P, const WfState &S, dim3 grid, size_t lds, hipStream_t stream)
 {
-    const uint32_t n = P.width * P.height;
-    const size_t lds = src == kSrcLds ? scene_lds_bytes(P.n_prims, P.n_lights) : 0;
-    // fixed grid: stage kernels stride over their queues
-    uint32_t blocks = (n + 255u) / 256u;
-    if (blocks > 2048u) blocks = 2048u;
-    const dim3 grid(blocks);
-    hipLaunchKernelGGL(k_wf_init, grid, dim3(256), 0, stream, P, S);
-    hipError_t e = hipGetLastError();
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wavefront<SRC, STATS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_wavefront<SRC, STATS>), grid, dim3(kWfThreads), lds, stream, P, S);
+    return hipGetLastError();
+}
 
-    // a pixel advances one segment per iteration: at most samples * (depth + 1) iterations
-    const uint64_t max_iters = (uint64_t)P.sample_count * ((uint64_t)P.ray_depth + 1u) + 2u;
-    const uint32_t batch = 32;
-    uint32_t it = 0;
-    uint32_t live = P.sample_count > 0 ? n : 0u;
-    while (live != 0u && it < max_iters) {
-        for (uint32_t k = 0; k < batch; ++k, ++it) {
-            if (src == kSrcLds) e = stats ? run_iteration<kSrcLds, true>(P, S, it, grid, lds, stream)
-                                          : run_iteration<kSrcLds, false>(P, S, it, grid, lds, stream);
-            else if (src == kSrcScalar) e = stats ? run_iteration<kSrcScalar, true>(P, S, it, grid, lds, stream)
-                                                  : run_iteration<kSrcScalar, false>(P, S, it, grid, lds, stream);
-            else e = stats ? run_iteration<kSrcBvh, true>(P, S, it, grid, lds, stream)
-                           : run_iteration<kSrcBvh, false>(P, S, it, grid, lds, stream);
-            if (e != hipSuccess) return e;
-        }
-        // live-path count as published by the last prepare of the batch, plus what that
-        // iteration produced: read the queue counters themselves
-        uint32_t counts[Q_COUNT + 1];
-        e = hipMemcpyAsync(counts, S.counts, sizeof(counts), hipMemcpyDeviceToHost, stream);
-        if (e != hipSuccess) return e;
-        e = hipStreamSynchronize(stream);
-        if (e != hipSuccess) return e;
-        const uint32_t nxt = it & 1u;  // the queues the last iteration filled
-        live = counts[Q_ACTIVE0 + nxt] + counts[Q_FRESH0 + nxt];
-    }
-    if (iterations_out) *iterations_out = it;
-    return hipSuccess;
+hipError_t launch_wavefront(const RenderParams &P, const WfState &S, int src, bool stats, hipStream_t stream)
+{
+    const uint32_t tiles = ((P.width + 7u) / 8u) * ((P.height + 7u) / 8u);
+    const dim3 grid((tiles + kWfTilesPerGroup - 1u) / kWfTilesPerGroup);
+    size_t lds = (sizeof(WfLds) + 15u) / 16u * 16u;
+    if (src == kSrcLds) lds += scene_lds_bytes(P.n_prims, P.n_lights);
+    if (src == kSrcLds) return stats ? launch_one<kSrcLds, true>(P, S, grid, lds, stream)
+                                     : launch_one<kSrcLds, false>(P, S, grid, lds, stream);
+    if (src == kSrcScalar) return stats ? launch_one<kSrcScalar, true>(P, S, grid, lds, stream)
+                                        : launch_one<kSrcScalar, false>(P, S, grid, lds, stream);
+    return stats ? launch_one<kSrcBvh, true>(P, S, grid, lds, stream)
+                 : launch_one<kSrcBvh, false>(P, S, grid, lds, stream);
 }
 
 }  // namespace rtx
