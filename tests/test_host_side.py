@@ -1,0 +1,196 @@
+"""The C++ host side (scene parser, tone map, PPM writer) against its checkers: the Python
+restatement of src/parser.rs in oracle/scene_text_oracle.py and the C oracle's
+src/image.rs restatement.  Runs without a GPU."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import scene_text_oracle as parser_oracle
+from raytracing_amd import _abi, host, reference_scene, dielectric_scene, synthetic_scene, scene_to_text
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# the reference's sample scene in its own syntax, including the trailing blank after the
+# ROTATION operands (assets/scene.txt:46) that yields an unused empty token
+SAMPLE = """DIMENSIONS 512 512
+RAY_DEPTH 6
+SAMPLES 10
+
+BG_COLOR 0 0 0
+
+CAMERA_POSITION 0 0 15
+CAMERA_RIGHT 1 0 0
+CAMERA_UP 0 1 0
+CAMERA_FORWARD 0 0 -1
+CAMERA_FOV_X 0.927295218
+
+NEW_PRIMITIVE
+PLANE 0 1 0
+POSITION 0 -5 0
+COLOR 1 1 1
+
+NEW_PRIMITIVE
+BOX 2 0.1 2
+POSITION 0 5 0
+EMISSION 2 2 2
+
+NEW_PRIMITIVE
+BOX 1.5 3 1.5
+POSITION -2 -2 -1
+ROTATION 0 0.3826834 0 0.9238795 
+COLOR 0.6 0.8 1
+
+NEW_PRIMITIVE
+ELLIPSOID 2 2 2
+POSITION 2 -3 2
+COLOR 1 0.8 0.6
+"""
+
+
+def same_scene(a, b, exact_rotation=True):
+    assert (a.width, a.height, a.ray_depth, a.n_samples) == (b.width, b.height, b.ray_depth, b.n_samples)
+    f = lambda v: np.asarray(v, dtype=np.float32).view(np.uint32).tolist()
+    for name in ("background", "cam_pos", "cam_right", "cam_up", "cam_forward"):
+        assert f(getattr(a, name)) == f(getattr(b, name)), name
+    assert f([a.fov_x]) == f([b.fov_x])
+    assert len(a.prims) == len(b.prims)
+    for p, q in zip(a.prims, b.prims):
+        assert (p.kind, p.material) == (q.kind, q.material)
+        for name in ("param", "position", "color", "emission"):
+            assert f(getattr(p, name)) == f(getattr(q, name)), name
+        if exact_rotation:
+            assert f(p.rotation) == f(q.rotation)
+        else:
+            assert np.allclose(p.rotation, q.rotation, rtol=0, atol=2e-7)
+        if p.material == _abi.DIELECTRIC:
+            assert f([p.ior]) == f([q.ior])
+
+
+def test_sample_scene_parses_like_the_oracle_and_the_listed_values():
+    got, tangents = host.parse_scene_text(SAMPLE, with_tangents=True)
+    want, want_tangents = parser_oracle.parse_scene_text(SAMPLE)
+    same_scene(got, want)
+    assert tangents == want_tangents == (0.5, 0.5)
+    ref = reference_scene()
+    same_scene(got.replace(prims=[]), ref.replace(prims=[]))
+    for k, ref_idx in enumerate((0, 5, 6, 7)):
+        same_scene(got.replace(prims=[got.prims[k]]), ref.replace(prims=[ref.prims[ref_idx]]))
+    assert got.light_indices() == [1]
+
+
+@pytest.mark.parametrize("make", [reference_scene, lambda: dielectric_scene(64, 48, 2, 16),
+                                  lambda: synthetic_scene(300, 5, 40, 30, 2, 4)])
+def test_written_scenes_round_trip(make, tmp_path):
+    sc = make()
+    text = scene_to_text(sc)
+    path = tmp_path / "scene.txt"
+    path.write_text(text)
+    got = host.parse_scene(str(path))
+    same_scene(got, parser_oracle.parse_scene_text(text)[0])
+    # ROTATION is normalised again on the way in (src/parser.rs:215-216): last-ulp drift only
+    same_scene(got, sc, exact_rotation=False)
+
+
+def test_statement_semantics():
+    head = ("DIMENSIONS 4 2\nRAY_DEPTH 3\nSAMPLES 1\nBG_COLOR 0.1 0.2 0.3\nCAMERA_POSITION 0 0 0\n"
+            "CAMERA_RIGHT 1 0 0\nCAMERA_UP 0 1 0\nCAMERA_FORWARD 0 0 1\nCAMERA_FOV_X 1.0\n")
+    body = ("SOMETHING_UNKNOWN 1 2 3\n\nPLANE 0 0 2\nIOR 1.7\nMETALLIC\nELLIPSOID 1 2 3 extra tokens\n"
+            "DIELECTRIC\nELLIPSOID 1 1 1\nDIELECTRIC\nIOR 1.5\nCOLOR 1e-1 .5 5.\nBOX 1 1 1\nROTATION 1 2 3 4\n"
+            "EMISSION +1 inf -0\nDIMENSIONS 8 2\n")
+    got, tangents = host.parse_scene_text(head + body, with_tangents=True)
+    want, want_t = parser_oracle.parse_scene_text(head + body)
+    same_scene(got, want)
+    assert tangents == want_t
+    p = got.prims
+    assert [x.kind for x in p] == [_abi.PLANE, _abi.ELLIPSOID, _abi.ELLIPSOID, _abi.BOX]
+    assert p[0].material == _abi.METALLIC and p[0].ior == 1.0          # IOR ignored: not dielectric yet
+    assert p[1].material == _abi.DIELECTRIC and p[1].ior == 1.0          # DIELECTRIC resets ior to 1
+    assert p[2].ior == 1.5 and p[2].color == (np.float32(0.1), 0.5, 5.0)
+    assert np.isclose(np.linalg.norm(p[3].rotation), 1.0, atol=1e-6) and p[3].emission[1] == np.inf
+    assert got.width == 8                                                # the later statement wins
+    assert tangents[1] == np.float32(np.float32(2) / np.float32(8)) * np.float32(tangents[0])
+    crlf = host.parse_scene_text((head + "PLANE 0 1 0\n").replace("\n", "\r\n"))
+    assert crlf.prims[0].param == (0.0, 1.0, 0.0)
+
+
+@pytest.mark.parametrize("bad", [
+    "PLANE 0 1\n",                      # missing operand
+    "PLANE 0  1 0\n",                   # doubled space: an empty token is read
+    "POSITION 0 0 0\nPLANE 0 1 0\n",    # modifier before any primitive
+    "PLANE 0 1 zero\n",                 # not a number
+    "PLANE 0 0x10 0\n",                 # hex is not accepted
+    "DIMENSIONS -4 4\n",                # usize
+    "SAMPLES 1.5\n",
+])
+def test_inputs_the_reference_panics_on(bad):
+    head = ("DIMENSIONS 4 2\nRAY_DEPTH 3\nSAMPLES 1\nBG_COLOR 0 0 0\nCAMERA_POSITION 0 0 0\n"
+            "CAMERA_RIGHT 1 0 0\nCAMERA_UP 0 1 0\nCAMERA_FORWARD 0 0 1\nCAMERA_FOV_X 1.0\n")
+    with pytest.raises(parser_oracle.Panic):
+        parser_oracle.parse_scene_text(head + bad)
+    with pytest.raises(host.SceneParseError):
+        host.parse_scene_text(head + bad)
+
+
+def test_missing_mandatory_lines():
+    lines = ("DIMENSIONS 4 2\nRAY_DEPTH 3\nSAMPLES 1\nBG_COLOR 0 0 0\nCAMERA_POSITION 0 0 0\n"
+             "CAMERA_RIGHT 1 0 0\nCAMERA_UP 0 1 0\nCAMERA_FORWARD 0 0 1\nCAMERA_FOV_X 1.0\n").splitlines(True)
+    for k in range(len(lines)):
+        text = "".join(lines[:k] + lines[k + 1:])
+        with pytest.raises(parser_oracle.Panic):
+            parser_oracle.parse_scene_text(text)
+        with pytest.raises(host.SceneParseError):
+            host.parse_scene_text(text)
+    with pytest.raises(host.SceneParseError):
+        host.parse_scene("/nonexistent/scene.txt")
+
+
+def test_tone_map_and_byte_conversion_match_the_oracle(oracle):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.uniform(0, 8, 20000), [0.0, 2.0, 1e-8, 1e6, np.inf, np.nan, -0.5, -0.0]]).astype(np.float32)
+    want = oracle.color_correction(x)
+    got = host.color_correction(x)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    assert np.array_equal(oracle.to_bytes(want), host.to_bytes(got))
+    assert host.to_bytes(host.color_correction(np.array([2.0], dtype=np.float32)))[0] == 245   # the light
+
+
+def test_ppm_writer(tmp_path, oracle):
+    rng = np.random.default_rng(1)
+    img = rng.uniform(0, 1.2, size=(5, 7, 3)).astype(np.float32)
+    path = tmp_path / "out.ppm"
+    host.write_ppm(str(path), img)
+    data = path.read_bytes()
+    header = b"P6\n7 5\n255\n"
+    assert data.startswith(header)
+    assert np.array_equal(np.frombuffer(data[len(header):], dtype=np.uint8), oracle.to_bytes(img).reshape(-1))
+
+
+def test_host_library_exports_every_declared_symbol():
+    import re
+    text = open(os.path.join(ROOT, "include", "rtx_host.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(rtx_host_[a-z_0-9]+)\s*\(", text))
+    lib = host.load_library()
+    assert names == set(host.SYMBOLS)
+    for n in names:
+        assert hasattr(lib, n)
+
+
+@pytest.mark.gpu
+def test_cli_renders_the_sample_scene(tmp_path, oracle):
+    """raytracing [scene] [out.ppm] (src/main.rs:33-42) end to end on the GPU."""
+    scene_path = tmp_path / "scene.txt"
+    scene_path.write_text(SAMPLE)
+    out = tmp_path / "out.ppm"
+    cli = os.path.join(ROOT, "raytracing_amd", "rtx_cli")
+    subprocess.check_call([cli, str(scene_path), str(out), "--size", "64", "48", "--spp", "4", "--seed", "3"])
+    data = out.read_bytes()
+    header = b"P6\n64 48\n255\n"
+    assert data.startswith(header)
+    got = np.frombuffer(data[len(header):], dtype=np.uint8).reshape(48, 64, 3)
+    sc = host.parse_scene_text(SAMPLE).replace(width=64, height=48, n_samples=4)
+    want = oracle.to_bytes(oracle.color_correction(oracle.render(sc, seed=3, order=oracle.ORDER_REFERENCE)))
+    assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
+    assert (got != want).mean() < 0.01
