@@ -151,15 +151,15 @@ int upload_scene(rtx_ctx *c)
     const size_t geom_bytes = align16(n * 3 * sizeof(float4));
     const size_t mat_bytes = align16(n * 3 * sizeof(float4));
     const size_t light_bytes = align16(nl * sizeof(int32_t));
+    const size_t lbound_bytes = align16(nl * sizeof(float4));
 
     rtx::BvhHost bvh;
     const bool want_bvh = c->src == rtx::kSrcBvh;
     if (want_bvh) rtx::build_bvh(c->prims.data(), (uint32_t)n, bvh);
     const size_t node_bytes = align16(bvh.nodes.size() * sizeof(float4));
-    const size_t pidx_bytes = align16(bvh.prim_index.size() * sizeof(int32_t));
     const size_t plane_bytes = align16(bvh.planes.size() * sizeof(int32_t));
 
-    const size_t total = geom_bytes + mat_bytes + light_bytes + node_bytes + pidx_bytes + plane_bytes + 16;
+    const size_t total = geom_bytes + mat_bytes + light_bytes + lbound_bytes + node_bytes + plane_bytes + 16;
     std::vector<unsigned char> host(total, 0);
     float4 *geom = reinterpret_cast<float4 *>(host.data());
     float4 *mat = reinterpret_cast<float4 *>(host.data() + geom_bytes);
@@ -188,11 +188,29 @@ int upload_scene(rtx_ctx *c)
         mat[3 * i + 2] = make_float4(p.color[0] / pi, p.color[1] / pi, p.color[2] / pi, area_pdf);
     }
     for (size_t i = 0; i < nl; ++i) lights[i] = c->lights[i];
-    size_t off_nodes = geom_bytes + mat_bytes + light_bytes;
-    size_t off_pidx = off_nodes + node_bytes, off_planes = off_pidx + pidx_bytes;
+    // bounding sphere per light: centre = position, radius = farthest surface point, inflated
+    const size_t off_lbound = geom_bytes + mat_bytes + light_bytes;
+    float4 *lbound = reinterpret_cast<float4 *>(host.data() + off_lbound);
+    for (size_t i = 0; i < nl; ++i) {
+        const rtx_prim &p = c->prims[(size_t)c->lights[i]];
+        double q2 = 0.0, r = 0.0;
+        for (int k = 0; k < 4; ++k) q2 += (double)p.rotation[k] * p.rotation[k];
+        if (p.kind == RTX_BOX) {
+            for (int k = 0; k < 3; ++k) r += (double)p.param[k] * p.param[k];
+            r = std::sqrt(r);
+        } else {
+            for (int k = 0; k < 3; ++k) r = std::fmax(r, std::fabs((double)p.param[k]));
+        }
+        // the rotation formula scales by |q|^2 when the quaternion is not exactly unit
+        r *= std::fmax(1.0, q2) * 1.02;
+        double r2 = r * r + 1e-6;
+        float r2f = (float)r2;
+        if (!(r2f >= 0.0f) || !std::isfinite(r2f)) r2f = INFINITY;  // never skipped
+        lbound[i] = make_float4(p.position[0], p.position[1], p.position[2], r2f);
+    }
+    size_t off_nodes = off_lbound + lbound_bytes;
+    size_t off_planes = off_nodes + node_bytes;
     if (!bvh.nodes.empty()) std::memcpy(host.data() + off_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(float4));
-    if (!bvh.prim_index.empty())
-        std::memcpy(host.data() + off_pidx, bvh.prim_index.data(), bvh.prim_index.size() * sizeof(int32_t));
     if (!bvh.planes.empty())
         std::memcpy(host.data() + off_planes, bvh.planes.data(), bvh.planes.size() * sizeof(int32_t));
 
@@ -211,6 +229,7 @@ int upload_scene(rtx_ctx *c)
     P.geom = reinterpret_cast<const float4 *>(base);
     P.mat = reinterpret_cast<const float4 *>(base + geom_bytes);
     P.lights = reinterpret_cast<const int32_t *>(base + geom_bytes + mat_bytes);
+    P.light_bounds = reinterpret_cast<const float4 *>(base + off_lbound);
     P.n_prims = (uint32_t)n;
     P.n_lights = (uint32_t)nl;
     const rtx_scene &s = c->scene;
@@ -227,7 +246,6 @@ int upload_scene(rtx_ctx *c)
     P.rng_const = c->opts.rng_mode == RTX_RNG_CONST ? 1u : 0u;
     std::memcpy(P.const_words, c->opts.const_words, sizeof(P.const_words));
     P.bvh.nodes = reinterpret_cast<const float4 *>(base + off_nodes);
-    P.bvh.prim_index = reinterpret_cast<const int32_t *>(base + off_pidx);
     P.bvh.planes = reinterpret_cast<const int32_t *>(base + off_planes);
     P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / 4);
     P.bvh.n_planes = (uint32_t)bvh.planes.size();

@@ -1,6 +1,6 @@
 // rtx_bvh.cpp -- BVH construction on the host: binned surface-area heuristic, binary tree,
-// leaves of up to kBvhLeafSize objects, depth capped at kBvhMaxDepth (deeper subtrees become
-// one large leaf), nodes emitted breadth-first.
+// one object per leaf, depth bounded by kBvhMaxDepth (balanced median splits take over where
+// a subtree could not fit otherwise), nodes emitted breadth-first.
 #include "rtx_bvh.h"
 
 #include <algorithm>
@@ -82,30 +82,32 @@ bool world_bounds(const rtx_prim &p, Box3 &out)
 
 struct BuildNode {
     Box3 box[2];
-    int32_t child[2];  // inner: index into the build-node array; leaf: first slot
-    int32_t count[2];  // 0 = inner (or empty when child < 0)
+    int32_t ref[2];  // >= 0: index into the build-node array; < 0: leaf of object ~ref
 };
+
+int ceil_log2(size_t n)
+{
+    int k = 0;
+    while (((size_t)1 << k) < n) ++k;
+    return k;
+}
 
 struct Builder {
     std::vector<Ref> refs;
     std::vector<BuildNode> nodes;
-    std::vector<int32_t> slots;
     int depth = 0;
 
-    // returns (child, count) describing refs[b, e)
-    void make(size_t b, size_t e, int level, int32_t &child, int32_t &count)
+    // returns the reference describing refs[b, e): a leaf or a new inner node
+    int32_t make(size_t b, size_t e, int level)
     {
-        depth = std::max(depth, level);
         const size_t n = e - b;
-        if (n <= (size_t)kBvhLeafSize || level >= kBvhMaxDepth) {
-            child = (int32_t)slots.size();
-            count = (int32_t)n;
-            for (size_t i = b; i < e; ++i) slots.push_back(refs[i].prim);
-            // keep leaf objects in index order: ties resolve towards the lowest index sooner
-            std::sort(slots.end() - (ptrdiff_t)n, slots.end());
-            return;
+        if (n == 1) {
+            depth = std::max(depth, level);
+            return ~refs[b].prim;
         }
-        size_t mid = split(b, e);
+        // a balanced split needs ceil(log2 n) more levels: use it when nothing else fits
+        const bool must_balance = level + ceil_log2(n) >= kBvhMaxDepth;
+        size_t mid = must_balance ? split_median(b, e) : split(b, e);
         int32_t me = (int32_t)nodes.size();
         nodes.emplace_back();
         BuildNode tmp;
@@ -113,11 +115,18 @@ struct Builder {
         tmp.box[1].clear();
         for (size_t i = b; i < mid; ++i) tmp.box[0].grow(refs[i].box);
         for (size_t i = mid; i < e; ++i) tmp.box[1].grow(refs[i].box);
-        make(b, mid, level + 1, tmp.child[0], tmp.count[0]);
-        make(mid, e, level + 1, tmp.child[1], tmp.count[1]);
+        tmp.ref[0] = make(b, mid, level + 1);
+        tmp.ref[1] = make(mid, e, level + 1);
         nodes[(size_t)me] = tmp;
-        child = me;
-        count = 0;
+        return me;
+    }
+
+    size_t split_median(size_t b, size_t e)
+    {
+        size_t mid = b + (e - b) / 2;
+        std::nth_element(refs.begin() + (ptrdiff_t)b, refs.begin() + (ptrdiff_t)mid, refs.begin() + (ptrdiff_t)e,
+                         [](const Ref &x, const Ref &y) { return x.prim < y.prim; });
+        return mid;
     }
 
     size_t split(size_t b, size_t e)
@@ -176,12 +185,8 @@ struct Builder {
         } else {
             mid = b;
         }
-        if (mid == b || mid == e) {
-            // all centres coincide (or binning failed): split by object index
-            mid = b + (e - b) / 2;
-            std::nth_element(refs.begin() + (ptrdiff_t)b, refs.begin() + (ptrdiff_t)mid, refs.begin() + (ptrdiff_t)e,
-                             [](const Ref &x, const Ref &y) { return x.prim < y.prim; });
-        }
+        // all centres coincide (or binning failed): split by object index
+        if (mid == b || mid == e) mid = split_median(b, e);
         return mid;
     }
 };
@@ -195,7 +200,6 @@ float int_bits(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
 void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
 {
     out.nodes.clear();
-    out.prim_index.clear();
     out.planes.clear();
     out.depth = 0;
     Builder bld;
@@ -211,32 +215,28 @@ void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
     }
     if (bld.refs.empty()) return;
 
-    int32_t root_child, root_count;
-    bld.make(0, bld.refs.size(), 0, root_child, root_count);
-    if (root_count > 0) {
-        // everything fits one leaf: a single node whose first child is that leaf
+    int32_t root = bld.make(0, bld.refs.size(), 0);
+    if (root < 0) {
+        // a single object: one node whose first child is that leaf
         BuildNode nd;
-        nd.box[0].clear();
+        nd.box[0] = bld.refs[0].box;
         nd.box[1].clear();
-        for (const Ref &r : bld.refs) nd.box[0].grow(r.box);
-        nd.child[0] = root_child;
-        nd.count[0] = root_count;
-        nd.child[1] = -1;
-        nd.count[1] = 0;
+        nd.ref[0] = root;
+        nd.ref[1] = kBvhEmpty;
         bld.nodes.push_back(nd);
-        root_child = (int32_t)bld.nodes.size() - 1;
+        root = (int32_t)bld.nodes.size() - 1;
     }
     // breadth-first renumbering
     std::vector<int32_t> order, new_index(bld.nodes.size(), -1);
     std::queue<int32_t> q;
-    q.push(root_child);
+    q.push(root);
     while (!q.empty()) {
         int32_t i = q.front();
         q.pop();
         new_index[(size_t)i] = (int32_t)order.size();
         order.push_back(i);
         for (int c = 0; c < 2; ++c)
-            if (bld.nodes[(size_t)i].count[c] == 0 && bld.nodes[(size_t)i].child[c] >= 0) q.push(bld.nodes[(size_t)i].child[c]);
+            if (bld.nodes[(size_t)i].ref[c] >= 0) q.push(bld.nodes[(size_t)i].ref[c]);
     }
     out.nodes.resize(order.size() * 4);
     for (size_t k = 0; k < order.size(); ++k) {
@@ -247,17 +247,13 @@ void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
                 lo[c][a] = round_down(nd.box[c].lo[a]);
                 hi[c][a] = round_up(nd.box[c].hi[a]);
             }
-        int32_t ch[2], cn[2];
-        for (int c = 0; c < 2; ++c) {
-            cn[c] = nd.count[c];
-            ch[c] = (nd.count[c] == 0 && nd.child[c] >= 0) ? new_index[(size_t)nd.child[c]] : nd.child[c];
-        }
+        int32_t ref[2];
+        for (int c = 0; c < 2; ++c) ref[c] = nd.ref[c] >= 0 ? new_index[(size_t)nd.ref[c]] : nd.ref[c];
         out.nodes[4 * k + 0] = make_float4(lo[0][0], lo[0][1], lo[0][2], hi[0][0]);
         out.nodes[4 * k + 1] = make_float4(hi[0][1], hi[0][2], lo[1][0], lo[1][1]);
         out.nodes[4 * k + 2] = make_float4(lo[1][2], hi[1][0], hi[1][1], hi[1][2]);
-        out.nodes[4 * k + 3] = make_float4(int_bits(ch[0]), int_bits(cn[0]), int_bits(ch[1]), int_bits(cn[1]));
+        out.nodes[4 * k + 3] = make_float4(int_bits(ref[0]), int_bits(ref[1]), 0.0f, 0.0f);
     }
-    out.prim_index = bld.slots;
     out.depth = bld.depth;
 }
 

@@ -12,9 +12,13 @@
 //   f[0] = lo0.x lo0.y lo0.z hi0.x
 //   f[1] = hi0.y hi0.z lo1.x lo1.y
 //   f[2] = lo1.z hi1.x hi1.y hi1.z
-//   f[3] = c0 n0 c1 n1 (int bits): n > 0 -> leaf slots [c, c+n) of prim_index;
-//                                  n = 0 -> inner node c (c >= 0) or empty (c < 0)
-// Nodes are stored in breadth-first order, so the first K nodes are the top levels.
+//   f[3] = ref0 ref1 - - (int bits): ref >= 0 -> inner node index; ref < 0 -> leaf holding
+//                                    object ~ref; kBvhEmpty -> no child
+// Every leaf holds exactly one object (an object test costs about five node tests, so
+// larger leaves lose).  Nodes are stored in breadth-first order, so the first K nodes are
+// the top levels.  The tree is at most kBvhMaxDepth deep: the builder switches from the
+// surface-area heuristic to balanced median splits where a subtree could otherwise exceed
+// it, so the traversal stack (one entry per level) cannot overflow.
 #pragma once
 #include "../../include/rtx.h"
 #include <hip/hip_runtime.h>
@@ -23,13 +27,12 @@
 
 namespace rtx {
 
-constexpr int kBvhMaxDepth = 28;   // the traversal stack holds one entry per level
+constexpr int kBvhMaxDepth = 30;
 constexpr int kBvhStackSize = 32;
-constexpr int kBvhLeafSize = 4;
+constexpr int32_t kBvhEmpty = INT32_MIN;
 
 struct BvhHost {
     std::vector<float4> nodes;       // 4 float4 per node
-    std::vector<int32_t> prim_index; // leaf slot -> object index
     std::vector<int32_t> planes;     // unbounded (or unboundable) objects, tested by every ray
     int depth = 0;
 };

@@ -42,7 +42,11 @@ RTX_DEV bool slab_test(V3 lo, V3 hi, V3 o, V3 inv, float t_limit, float &t_near)
     return tn <= tf && !(tn > t_limit);
 }
 
-// BLOCK = threads per workgroup of the calling kernel (the stack array is sized for it)
+// BLOCK = threads per workgroup of the calling kernel (the stack array is sized for it).
+//
+// The loop alternates two phases so that the expensive, kind-dependent object test is not
+// interleaved with the cheap node steps: every lane first descends until it holds a leaf (or
+// has finished), then all lanes holding a leaf test their object together.
 template <bool STATS, int BLOCK = 256>
 RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, float &best_t, Counters<STATS> &cnt)
 {
@@ -58,44 +62,41 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
 
     const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     int sp = 0;
-    int node = 0;
-    while (true) {
-        const float4 *nd = B.nodes + 4 * (size_t)node;
-        float4 f0 = nd[0], f1 = nd[1], f2 = nd[2], f3 = nd[3];
-        int c0 = __float_as_int(f3.x), n0 = __float_as_int(f3.y);
-        int c1 = __float_as_int(f3.z), n1 = __float_as_int(f3.w);
-        float d0, d1;
-        bool h0 = (n0 > 0 || c0 >= 0) && slab_test(v3(f0.x, f0.y, f0.z), v3(f0.w, f1.x, f1.y), o, inv, best_t, d0);
-        bool h1 = (n1 > 0 || c1 >= 0) && slab_test(v3(f1.z, f1.w, f2.x), v3(f2.y, f2.z, f2.w), o, inv, best_t, d1);
-        if constexpr (STATS) cnt.v[C_NODE_TESTS] += 2;
-        if (h0 && n0 > 0) {
-            for (int k = 0; k < n0; ++k)
-                bvh_try_object<STATS>(tab, B.prim_index[c0 + k], o, d, ray_length, best, best_t, cnt);
-            h0 = false;
-        }
-        if (h1 && n1 > 0) {
-            // the first leaf may have shortened the ray
-            if (!(d1 > best_t))
-                for (int k = 0; k < n1; ++k)
-                    bvh_try_object<STATS>(tab, B.prim_index[c1 + k], o, d, ray_length, best, best_t, cnt);
-            h1 = false;
-        }
-        if (h0 && h1) {
-            bool first0 = d0 <= d1;
-            int near_c = first0 ? c0 : c1, far_c = first0 ? c1 : c0;
-            if (sp < kBvhStackSize) {
-                stack[sp * BLOCK] = far_c;
+    int32_t cur = 0;  // >= 0 inner node, < 0 leaf of object ~cur, kBvhEmpty = finished
+    for (;;) {
+        while (cur >= 0) {
+            const float4 *nd = B.nodes + 4 * (size_t)cur;
+            float4 f0 = nd[0], f1 = nd[1], f2 = nd[2], f3 = nd[3];
+            const int32_t r0 = __float_as_int(f3.x), r1 = __float_as_int(f3.y);
+            float d0, d1;
+            bool h0 = r0 != kBvhEmpty && slab_test(v3(f0.x, f0.y, f0.z), v3(f0.w, f1.x, f1.y), o, inv, best_t, d0);
+            bool h1 = r1 != kBvhEmpty && slab_test(v3(f1.z, f1.w, f2.x), v3(f2.y, f2.z, f2.w), o, inv, best_t, d1);
+            if constexpr (STATS) cnt.v[C_NODE_TESTS] += 2;
+            if (h0 && h1) {
+                const bool first0 = d0 <= d1;
+                stack[sp * BLOCK] = first0 ? r1 : r0;   // depth <= kBvhMaxDepth < kBvhStackSize
                 sp++;
+                cur = first0 ? r0 : r1;
+            } else if (h0) {
+                cur = r0;
+            } else if (h1) {
+                cur = r1;
+            } else if (sp > 0) {
+                sp--;
+                cur = stack[sp * BLOCK];
+            } else {
+                cur = kBvhEmpty;
             }
-            node = near_c;
-        } else if (h0) {
-            node = c0;
-        } else if (h1) {
-            node = c1;
-        } else {
-            if (sp == 0) break;
-            sp--;
-            node = stack[sp * BLOCK];
+        }
+        if (__ballot(cur != kBvhEmpty) == 0ull) break;
+        if (cur != kBvhEmpty) {
+            bvh_try_object<STATS>(tab, ~cur, o, d, ray_length, best, best_t, cnt);
+            if (sp > 0) {
+                sp--;
+                cur = stack[sp * BLOCK];
+            } else {
+                cur = kBvhEmpty;
+            }
         }
     }
     return best;

@@ -9,6 +9,7 @@
 //   mat[3*i+2]  = color / pi (IEEE division at upload),      /
 //                 w = 1 / (8 (ab + bc + ac)) for a box (its surface pdf), else 0
 //   lights[k]   = object index of light k (emissive ellipsoids and boxes, object order)
+//   light_bounds[k] = bounding sphere of light k: centre xyz, squared radius inflated by 2 %
 // The scan data and the shading data are separate arrays so that the scan streams 48
 // contiguous bytes per object and never touches colours.
 #pragma once
@@ -32,7 +33,6 @@ enum : int {
 
 struct BvhView {
     const float4 *nodes;   // 4 float4 per node, see rtx_bvh.h
-    const int32_t *prim_index; // leaf slots -> object index
     const int32_t *planes; // objects that are tested for every ray
     uint32_t n_nodes, n_planes;
 };
@@ -42,6 +42,7 @@ struct RenderParams {
     const float4 *geom;
     const float4 *mat;
     const int32_t *lights;
+    const float4 *light_bounds;  // per light: bounding-sphere centre, squared radius
     uint32_t n_prims, n_lights;
     uint32_t width, height, ray_depth;
     uint32_t sample_first, sample_count;

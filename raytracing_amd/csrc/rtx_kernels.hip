@@ -36,6 +36,7 @@ RTX_DEV Table stage_table_lds(const RenderParams &P)
     t.geom = rtx_smem;
     t.mat = rtx_smem + ng;
     t.lights = sl;
+    t.light_bounds = P.light_bounds;
     t.n_prims = P.n_prims;
     t.n_lights = P.n_lights;
     return t;
@@ -46,6 +47,7 @@ RTX_DEV Table global_table(const RenderParams &P)
     t.geom = P.geom;
     t.mat = P.mat;
     t.lights = P.lights;
+    t.light_bounds = P.light_bounds;
     t.n_prims = P.n_prims;
     t.n_lights = P.n_lights;
     return t;

@@ -40,6 +40,7 @@ struct Table {
     const float4 *geom;
     const float4 *mat;
     const int32_t *lights;
+    const float4 *light_bounds;  // per light: bounding-sphere centre xyz, squared radius (inflated)
     uint32_t n_prims, n_lights;
 };
 
@@ -225,11 +226,14 @@ RTX_DEV Hit finish_hit(const Table &tab, int idx, V3 o, V3 d, float t, bool want
 // |cos| between the ray and the surface normal there (src/random.rs:120).  The reference flips
 // the normal against the ray first (src/objects/geometry.rs:31-33); negating a vector negates
 // its dot product exactly, so the absolute value is taken of the unflipped one.
-// `g` is wave-uniform (the light loop index is).
+// UNIFORM: `g` is the same object in every lane (the light loop index is wave-uniform), which
+// allows the identity-rotation shortcuts; otherwise every lane may hold a different light.
+template <bool UNIFORM>
 RTX_DEV bool light_intersect_cos(const Geom &g, V3 o, V3 d, float &t, float &cosv)
 {
-    const bool ident = (__builtin_amdgcn_readfirstlane(g.flags) & kGeomIdentity) &&
-                       __ballot(!ray_is_plain(o, d)) == 0ull;
+    bool ident = false;
+    if constexpr (UNIFORM)
+        ident = (__builtin_amdgcn_readfirstlane(g.flags) & kGeomIdentity) && __ballot(!ray_is_plain(o, d)) == 0ull;
     LocalRay lr = ident ? to_local_identity(g, o, d) : to_local(g, o, d);
     if (!figure_t(g.kind, g.param, lr, t)) return false;
     if (ident && __builtin_amdgcn_readfirstlane(g.kind) == kBox) {
@@ -273,37 +277,92 @@ RTX_DEV float intersection_pdf(const Geom &g, float box_area_pdf, V3 o, V3 d, fl
     float pdf = light_area_pdf(g, box_area_pdf, obj_point) * dist / cosv;
     return finite_f(pdf) ? pdf : 0.0f;
 }
-// src/random.rs:83-109: every light is intersected by the ray from p along d, and again
-// from just behind the first hit, to collect the far side of the surface.
+// src/random.rs:83-109.  Returns the sum over lights divided by their number.
+//
+// With many lights almost every (ray, light) pair is a miss.  A ray that passes a light's
+// bounding sphere (radius inflated by 2 %, far above any rounding of the exact test) at a
+// distance cannot hit the light, and a miss adds nothing to the sum, so such lights are
+// skipped: each lane first collects the lights whose sphere its ray touches in a bit mask
+// (wave-uniform loop, ~20 instructions per light), then the lanes work through their own
+// candidates, lowest index first, which keeps the order of the additions.
 template <bool STATS>
 RTX_DEV float light_pdf(const Table &tab, V3 p, V3 dir, Counters<STATS> &cnt)
 {
     if (tab.n_lights == 0) return 0.0f;
     V3 d = normalize(dir);
     float pdf = 0.0f;
-    for (uint32_t li = 0; li < tab.n_lights; ++li) {
-        const uint32_t lidx = (uint32_t)tab.lights[li];
-        Geom g = load_geom(tab.geom, lidx);
-        const float box_area_pdf = tab.mat[3 * lidx + 2].w;
-        cnt.template add<C_LTEST_ELLIPSOID>(g.kind == kEllipsoid);
-        cnt.template add<C_LTEST_BOX>(g.kind == kBox);
-        float t1, t2, c1, c2;
-        if (!light_intersect_cos(g, p, d, t1, c1)) {
-            cnt.template add<C_LPDF_0>();
-            continue;
+    if (tab.n_lights <= 2) {
+        for (uint32_t li = 0; li < tab.n_lights; ++li) {
+            const uint32_t lidx = (uint32_t)tab.lights[li];
+            Geom g = load_geom(tab.geom, lidx);
+            const float box_area_pdf = tab.mat[3 * lidx + 2].w;
+            cnt.template add<C_LTEST_ELLIPSOID>(g.kind == kEllipsoid);
+            cnt.template add<C_LTEST_BOX>(g.kind == kBox);
+            float t1, t2, c1, c2;
+            if (!light_intersect_cos<true>(g, p, d, t1, c1)) {
+                cnt.template add<C_LPDF_0>();
+                continue;
+            }
+            pdf += intersection_pdf(g, box_area_pdf, p, d, t1, c1, p);
+            // Ray::new_shifted normalises the (already unit) direction once more
+            V3 d2 = normalize(d);
+            V3 o2 = (p + d * t1) + d2 * kRayEps;
+            cnt.template add<C_LTEST_ELLIPSOID>(g.kind == kEllipsoid);
+            cnt.template add<C_LTEST_BOX>(g.kind == kBox);
+            if (!light_intersect_cos<true>(g, o2, d2, t2, c2)) {
+                cnt.template add<C_LPDF_1>();
+                continue;
+            }
+            pdf += intersection_pdf(g, box_area_pdf, o2, d2, t2, c2, p);
+            cnt.template add<C_LPDF_2>();
         }
-        pdf += intersection_pdf(g, box_area_pdf, p, d, t1, c1, p);
-        // Ray::new_shifted normalises the (already unit) direction once more
-        V3 d2 = normalize(d);
-        V3 o2 = (p + d * t1) + d2 * kRayEps;
-        cnt.template add<C_LTEST_ELLIPSOID>(g.kind == kEllipsoid);
-        cnt.template add<C_LTEST_BOX>(g.kind == kBox);
-        if (!light_intersect_cos(g, o2, d2, t2, c2)) {
-            cnt.template add<C_LPDF_1>();
-            continue;
+    } else {
+        for (uint32_t chunk = 0; chunk < tab.n_lights; chunk += 64u) {
+            const uint32_t n = tab.n_lights - chunk < 64u ? tab.n_lights - chunk : 64u;
+            unsigned long long candidates = 0ull;
+            for (uint32_t k = 0; k < n; ++k) {
+                const float4 b = tab.light_bounds[chunk + k];
+                V3 oc = v3(b.x, b.y, b.z) - p;
+                float along = dot(oc, d);
+                float oc2 = dot(oc, oc);
+                float dist2 = oc2 - along * along;
+                // written so that a NaN never skips a light
+                bool skip = (dist2 > b.w + 2e-6f * oc2) || (along < 0.0f && oc2 > b.w);
+                if (!skip) candidates |= 1ull << k;
+                if constexpr (STATS) {
+                    // a skipped light is a light the reference tested and missed
+                    int kind = __float_as_int(tab.geom[3 * tab.lights[chunk + k] + 1].w) & 0xff;
+                    cnt.template add<C_LTEST_ELLIPSOID>(skip && kind == kEllipsoid);
+                    cnt.template add<C_LTEST_BOX>(skip && kind == kBox);
+                    cnt.template add<C_LPDF_0>(skip);
+                }
+            }
+            while (candidates != 0ull) {
+                const uint32_t k = (uint32_t)__builtin_ctzll(candidates);
+                candidates &= candidates - 1ull;
+                const uint32_t lidx = (uint32_t)tab.lights[chunk + k];
+                Geom g = load_geom(tab.geom, lidx);
+                const float box_area_pdf = tab.mat[3 * lidx + 2].w;
+                cnt.template add<C_LTEST_ELLIPSOID>(g.kind == kEllipsoid);
+                cnt.template add<C_LTEST_BOX>(g.kind == kBox);
+                float t1, t2, c1, c2;
+                if (!light_intersect_cos<false>(g, p, d, t1, c1)) {
+                    cnt.template add<C_LPDF_0>();
+                    continue;
+                }
+                pdf += intersection_pdf(g, box_area_pdf, p, d, t1, c1, p);
+                V3 d2 = normalize(d);
+                V3 o2 = (p + d * t1) + d2 * kRayEps;
+                cnt.template add<C_LTEST_ELLIPSOID>(g.kind == kEllipsoid);
+                cnt.template add<C_LTEST_BOX>(g.kind == kBox);
+                if (!light_intersect_cos<false>(g, o2, d2, t2, c2)) {
+                    cnt.template add<C_LPDF_1>();
+                    continue;
+                }
+                pdf += intersection_pdf(g, box_area_pdf, o2, d2, t2, c2, p);
+                cnt.template add<C_LPDF_2>();
+            }
         }
-        pdf += intersection_pdf(g, box_area_pdf, o2, d2, t2, c2, p);
-        cnt.template add<C_LPDF_2>();
     }
     // x / 1.0f is x: the division is skipped for a single light
     return tab.n_lights == 1 ? pdf : pdf / (float)tab.n_lights;

@@ -144,6 +144,7 @@ __global__ void __launch_bounds__(kWfThreads) k_wavefront(const RenderParams P, 
     Table tab;
     tab.n_prims = P.n_prims;
     tab.n_lights = P.n_lights;
+    tab.light_bounds = P.light_bounds;
     if constexpr (SRC == kSrcLds) {
         float4 *tbl = rtx_smem + (sizeof(WfLds) + 15u) / 16u;
         const uint32_t ng = 3u * P.n_prims, nm = 3u * P.n_prims;
