@@ -67,6 +67,8 @@ struct PrimaryParams {
 
 // launchers implemented in the .hip files
 enum : int { kSrcLds = 0, kSrcScalar = 1, kSrcBvh = 2 };
+// scenes with more than kFewLights lights run the kernels built with the candidate-mask light pdf
+constexpr uint32_t kFewLights = 2;
 hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, hipStream_t stream);
 hipError_t launch_primary(const RenderParams &p, const PrimaryParams &out, int src, hipStream_t stream);
 hipError_t launch_divide(float *d, uint64_t n, float divisor, hipStream_t stream);

@@ -72,9 +72,9 @@ RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, flo
 }
 
 #ifndef RTX_MEGAKERNEL_ATTR
-#define RTX_MEGAKERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))  // at most 128 VGPRs: 4 waves per SIMD measured fastest
+#define RTX_MEGAKERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))  // at most 128 VGPRs: 4 waves per SIMD measured fastest for the scan and the BVH kernels alike
 #endif
-template <int SRC, bool STATS>
+template <int SRC, bool STATS, bool MANY_LIGHTS>
 __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const RenderParams P)
 {
     Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
                 cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
                 cnt.template add<C_HIT_BOX>(kind == kBox);
             }
-            done = scatter<STATS>(P, tab, p, idx, t, pixel, s, cnt);
+            done = scatter<STATS, MANY_LIGHTS>(P, tab, p, idx, t, pixel, s, cnt);
         }
         if (done) {
             sum = sum + p.L;
@@ -173,20 +173,27 @@ static dim3 tile_grid(const RenderParams &p)
     return dim3((tiles + 3u) / 4u);
 }
 
+template <int SRC>
+static void launch_megakernel_src(const RenderParams &p, bool stats, dim3 grid, size_t lds, hipStream_t stream)
+{
+    const dim3 block(256);
+    const bool many = p.n_lights > kFewLights;
+    if (stats) {
+        if (many) hipLaunchKernelGGL((k_megakernel<SRC, true, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((k_megakernel<SRC, true, false>), grid, block, lds, stream, p);
+    } else {
+        if (many) hipLaunchKernelGGL((k_megakernel<SRC, false, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((k_megakernel<SRC, false, false>), grid, block, lds, stream, p);
+    }
+}
+
 hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, hipStream_t stream)
 {
-    dim3 grid = tile_grid(p), block(256);
-    size_t lds = src == kSrcLds ? scene_lds_bytes(p.n_prims, p.n_lights) : 0;
-    if (src == kSrcLds) {
-        if (stats) hipLaunchKernelGGL((k_megakernel<kSrcLds, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((k_megakernel<kSrcLds, false>), grid, block, lds, stream, p);
-    } else if (src == kSrcScalar) {
-        if (stats) hipLaunchKernelGGL((k_megakernel<kSrcScalar, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((k_megakernel<kSrcScalar, false>), grid, block, lds, stream, p);
-    } else {
-        if (stats) hipLaunchKernelGGL((k_megakernel<kSrcBvh, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((k_megakernel<kSrcBvh, false>), grid, block, lds, stream, p);
-    }
+    const dim3 grid = tile_grid(p);
+    const size_t lds = src == kSrcLds ? scene_lds_bytes(p.n_prims, p.n_lights) : 0;
+    if (src == kSrcLds) launch_megakernel_src<kSrcLds>(p, stats, grid, lds, stream);
+    else if (src == kSrcScalar) launch_megakernel_src<kSrcScalar>(p, stats, grid, lds, stream);
+    else launch_megakernel_src<kSrcBvh>(p, stats, grid, lds, stream);
     return hipGetLastError();
 }
 

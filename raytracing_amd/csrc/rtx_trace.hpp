@@ -285,13 +285,15 @@ RTX_DEV float intersection_pdf(const Geom &g, float box_area_pdf, V3 o, V3 d, fl
 // skipped: each lane first collects the lights whose sphere its ray touches in a bit mask
 // (wave-uniform loop, ~20 instructions per light), then the lanes work through their own
 // candidates, lowest index first, which keeps the order of the additions.
-template <bool STATS>
+// MANY_LIGHTS selects the candidate-mask form at compile time (kernels are instantiated both
+// ways and the launcher picks by light count), so few-light scenes do not carry its registers.
+template <bool STATS, bool MANY_LIGHTS>
 RTX_DEV float light_pdf(const Table &tab, V3 p, V3 dir, Counters<STATS> &cnt)
 {
     if (tab.n_lights == 0) return 0.0f;
     V3 d = normalize(dir);
     float pdf = 0.0f;
-    if (tab.n_lights <= 2) {
+    if constexpr (!MANY_LIGHTS) {
         for (uint32_t li = 0; li < tab.n_lights; ++li) {
             const uint32_t lidx = (uint32_t)tab.lights[li];
             Geom g = load_geom(tab.geom, lidx);
@@ -368,7 +370,7 @@ RTX_DEV float light_pdf(const Table &tab, V3 p, V3 dir, Counters<STATS> &cnt)
     return tab.n_lights == 1 ? pdf : pdf / (float)tab.n_lights;
 }
 // src/random.rs:143-161
-template <bool STATS>
+template <bool STATS, bool MANY_LIGHTS>
 RTX_DEV float mis_pdf(const Table &tab, V3 p, V3 n, V3 d, Counters<STATS> &cnt)
 {
     float a = tab.n_lights == 0 ? 1.0f : 0.5f;
@@ -376,7 +378,7 @@ RTX_DEV float mis_pdf(const Table &tab, V3 p, V3 n, V3 d, Counters<STATS> &cnt)
 #if defined(RTX_ABLATE) && RTX_ABLATE == 1
     return cos_pdf * a + (p.x * 1e-9f + 0.05f) * (1.0f - a);
 #endif
-    return cos_pdf * a + light_pdf<STATS>(tab, p, d, cnt) * (1.0f - a);
+    return cos_pdf * a + light_pdf<STATS, MANY_LIGHTS>(tab, p, d, cnt) * (1.0f - a);
 }
 
 // ------------------------------------------------------------------ sampling
@@ -506,7 +508,7 @@ RTX_DEV bool surface_emission(const RenderParams &P, const Table &tab, Path &p, 
 // ray: picks the next ray and updates the throughput.  Returns true when the path ends
 // here (a rejected diffuse sample).  `material` is the object's material; kernels that
 // run one material per launch pass it as a constant.
-template <bool STATS>
+template <bool STATS, bool MANY_LIGHTS>
 RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, float t, int material,
                     uint32_t pixel, uint32_t sample, Counters<STATS> &cnt)
 {
@@ -550,7 +552,7 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
         }
         if (dot(new_dir, n) < 0.0f) return true;
         cnt.template add<C_PDF_EVALS>();
-        float pdf = mis_pdf<STATS>(tab, point, n, new_dir, cnt);
+        float pdf = mis_pdf<STATS, MANY_LIGHTS>(tab, point, n, new_dir, cnt);
         if (!finite_f(pdf) || pdf < 1e-6f) return true;
         V3 nd = normalize(new_dir);
         float cosv = dot(n, nd);
@@ -592,13 +594,13 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
 }
 
 // One whole surface interaction (emission, depth cut, material switch); true = path ended.
-template <bool STATS>
+template <bool STATS, bool MANY_LIGHTS>
 RTX_DEV bool scatter(const RenderParams &P, const Table &tab, Path &p, int idx, float t,
                      uint32_t pixel, uint32_t sample, Counters<STATS> &cnt)
 {
     if (surface_emission(P, tab, p, idx)) return true;
     int material = __float_as_int(tab.mat[3 * idx + 0].w);
-    return bounce<STATS>(P, tab, p, idx, t, material, pixel, sample, cnt);
+    return bounce<STATS, MANY_LIGHTS>(P, tab, p, idx, t, material, pixel, sample, cnt);
 }
 
 }  // namespace rtx

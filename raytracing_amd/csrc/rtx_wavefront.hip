@@ -103,7 +103,7 @@ RTX_DEV bool wf_finish_path(const RenderParams &P, const WfState &S, uint32_t sl
 }
 
 // one material's queue: scatter (src/trace.rs:25-68 for that material)
-template <int MATERIAL, bool STATS>
+template <int MATERIAL, bool STATS, bool MANY_LIGHTS>
 RTX_DEV void wf_shade(const RenderParams &P, const WfState &S, WfLds &L, const Table &tab, uint32_t nxt,
                       Counters<STATS> &cnt)
 {
@@ -120,7 +120,7 @@ RTX_DEV void wf_shade(const RenderParams &P, const WfState &S, WfLds &L, const T
             const uint32_t pixel = py * P.width + px;
             const uint32_t slot = blockIdx.x * kWfPixelsPerGroup + local;
             Path p = wf_load_path(S, slot);
-            const bool ended = bounce<STATS>(P, tab, p, S.hit_idx[slot], S.hit_t[slot], MATERIAL, pixel,
+            const bool ended = bounce<STATS, MANY_LIGHTS>(P, tab, p, S.hit_idx[slot], S.hit_t[slot], MATERIAL, pixel,
                                              S.sample[slot], cnt);
             if (ended) {
                 refresh = wf_finish_path(P, S, slot, pixel, p.L);
@@ -136,7 +136,7 @@ RTX_DEV void wf_shade(const RenderParams &P, const WfState &S, WfLds &L, const T
     }
 }
 
-template <int SRC, bool STATS>
+template <int SRC, bool STATS, bool MANY_LIGHTS>
 __global__ void __launch_bounds__(kWfThreads) k_wavefront(const RenderParams P, const WfState S)
 {
     // dynamic LDS: [queues + counters][object table when SRC == kSrcLds]
@@ -275,9 +275,9 @@ __global__ void __launch_bounds__(kWfThreads) k_wavefront(const RenderParams P, 
         __syncthreads();
 
         // ---- shade, one material at a time
-        wf_shade<kDiffuse, STATS>(P, S, L, tab, nxt, cnt);
-        wf_shade<kMetallic, STATS>(P, S, L, tab, nxt, cnt);
-        wf_shade<kDielectric, STATS>(P, S, L, tab, nxt, cnt);
+        wf_shade<kDiffuse, STATS, MANY_LIGHTS>(P, S, L, tab, nxt, cnt);
+        wf_shade<kMetallic, STATS, MANY_LIGHTS>(P, S, L, tab, nxt, cnt);
+        wf_shade<kDielectric, STATS, MANY_LIGHTS>(P, S, L, tab, nxt, cnt);
         __syncthreads();
 
         if (L.count[Q_ACTIVE0 + nxt] + L.count[Q_FRESH0 + nxt] == 0u) break;
@@ -320,14 +320,20 @@ void wavefront_bind_state(void *block, uint32_t width, uint32_t height, WfState 
     S.hit_idx = reinterpret_cast<int32_t *>(next());
 }
 
+template <int SRC, bool STATS, bool MANY_LIGHTS>
+static hipError_t launch_variant(const RenderParams &P, const WfState &S, dim3 grid, size_t lds, hipStream_t stream)
+{
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wavefront<SRC, STATS, MANY_LIGHTS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_wavefront<SRC, STATS, MANY_LIGHTS>), grid, dim3(kWfThreads), lds, stream, P, S);
+    return hipGetLastError();
+}
 template <int SRC, bool STATS>
 static hipError_t launch_one(const RenderParams &P, const WfState &S, dim3 grid, size_t lds, hipStream_t stream)
 {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wavefront<SRC, STATS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_wavefront<SRC, STATS>), grid, dim3(kWfThreads), lds, stream, P, S);
-    return hipGetLastError();
+    return P.n_lights > kFewLights ? launch_variant<SRC, STATS, true>(P, S, grid, lds, stream)
+                                   : launch_variant<SRC, STATS, false>(P, S, grid, lds, stream);
 }
 
 hipError_t launch_wavefront(const RenderParams &P, const WfState &S, int src, bool stats, hipStream_t stream)
