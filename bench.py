@@ -70,6 +70,24 @@ def cpu_baseline(scene, seconds_target=15.0):
             "host_cpus": os.cpu_count()}
 
 
+def measured_traffic(workload, mode, n_gpus):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary
+    of this workload (profiles/<round>/<workload>_<mode>_pmc.json: FETCH_SIZE and WRITE_SIZE in
+    KiB, FETCH_SIZE doubled as the gfx950 counter reports half of a streamed read).  PMC
+    passes cannot run inside the timed bench, so this is read back, not measured live."""
+    import glob
+    if n_gpus != 1:
+        return None, None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"{workload}_{mode}_pmc.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    if "FETCH_SIZE" not in d or "WRITE_SIZE" not in d:
+        return None, None
+    return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, os.path.relpath(files[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,8 +184,9 @@ def main():
     if stats is not None:
         flops_rank = algorithmic_flops(stats, stats.get("bvh_node_tests", 0))
         achieved = flops_rank / (kernel_ms * 1e-3) / 1e12
+        traffic, traffic_src = measured_traffic(name, args.mode, world)
         roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": None,
+                    "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "frac_of_nonpacked_fma_peak": achieved / PEAK_FP32_NONPACKED_TFLOPS,
                     "kernel": "k_megakernel" if mode == _abi.MODE_MEGAKERNEL else "wavefront stages",
                     "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_rank,
@@ -184,7 +203,7 @@ def main():
             "metric": "Msamples/sec (whole node)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if name == "c4" else "weak", "vs_baseline": None,
+            "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{name}: {desc}", "mode": args.mode, "accel": args.accel, "seed": args.seed,
                        "samples_per_step": total_samples,

@@ -4,16 +4,14 @@
 
 namespace rtx {
 
-// Structure-of-arrays path state in device memory, one entry per slot (workgroup * 4096 +
-// workgroup-local pixel number).
+// Path state in device memory: one 64-byte record per slot (slot = workgroup * 4096 +
+// workgroup-local pixel number), so a path's whole state is one cache line:
+//   rec[4*slot+0] = ray origin xyz      | distance of the current segment's closest hit
+//   rec[4*slot+1] = ray direction xyz   | object index of that hit (int bits)
+//   rec[4*slot+2] = throughput xyz      | depth (int bits)
+//   rec[4*slot+3] = radiance so far xyz | global index of the sample in flight (int bits)
 struct WfState {
-    float *ray[6];     // origin xyz, direction xyz
-    float *thr[3];     // throughput
-    float *rad[3];     // radiance gathered by the current sample
-    uint32_t *depth;
-    uint32_t *sample;  // global index of the sample the pixel is working on
-    float *hit_t;      // closest hit of the current segment
-    int32_t *hit_idx;
+    float4 *rec;
 };
 
 size_t wavefront_state_bytes(uint32_t width, uint32_t height);

@@ -8,10 +8,11 @@
 // no host round trips.  A pixel has at most one path in flight, so its samples are still
 // accumulated in sample order and the image is bit-identical to the megakernel's.
 //
-// Path state is structure-of-arrays in HBM (64 B per pixel), indexed by SLOT = workgroup *
-// 4096 + workgroup-local pixel number, so the lanes of a wave -- which hold consecutive queue
-// entries, i.e. nearly consecutive local numbers -- read and write contiguous addresses; only
-// the radiance sum (the output buffer) is indexed by pixel.  Queues hold 16-bit local numbers.
+// Path state is one 64-byte record per pixel in HBM (rtx_wavefront.h), indexed by SLOT =
+// workgroup * 4096 + workgroup-local pixel number: a stage reads and writes whole cache lines
+// whatever order the compacted queue hands the paths out in (a structure-of-arrays layout
+// measured 2 KB of HBM traffic per path segment and ran at the HBM roof).  Only the radiance
+// sum (the output buffer) is indexed by pixel.  Queues hold 16-bit local numbers.
 // One iteration of the in-kernel loop advances every live path of the workgroup by one
 // segment:
 //   generate  fresh queue  -> primary ray of the pixel's next sample -> active queue
@@ -67,39 +68,51 @@ RTX_DEV bool wf_pixel(const RenderParams &P, uint32_t local, uint32_t &px, uint3
     return px < P.width && py < P.height;
 }
 
-RTX_DEV Path wf_load_path(const WfState &S, uint32_t px)
-{
+struct WfPath {
     Path p;
-    p.o = v3(S.ray[0][px], S.ray[1][px], S.ray[2][px]);
-    p.d = v3(S.ray[3][px], S.ray[4][px], S.ray[5][px]);
-    p.T = v3(S.thr[0][px], S.thr[1][px], S.thr[2][px]);
-    p.L = v3(S.rad[0][px], S.rad[1][px], S.rad[2][px]);
-    p.depth = S.depth[px];
-    return p;
-}
-RTX_DEV void wf_store_ray(const WfState &S, uint32_t px, const Path &p)
+    float hit_t;
+    int hit_idx;
+    uint32_t sample;
+};
+RTX_DEV WfPath wf_load(const WfState &S, uint32_t slot)
 {
-    S.ray[0][px] = p.o.x; S.ray[1][px] = p.o.y; S.ray[2][px] = p.o.z;
-    S.ray[3][px] = p.d.x; S.ray[4][px] = p.d.y; S.ray[5][px] = p.d.z;
+    const float4 *r = S.rec + 4ull * slot;
+    float4 a = r[0], b = r[1], c = r[2], e = r[3];
+    WfPath w;
+    w.p.o = v3(a.x, a.y, a.z);
+    w.p.d = v3(b.x, b.y, b.z);
+    w.p.T = v3(c.x, c.y, c.z);
+    w.p.L = v3(e.x, e.y, e.z);
+    w.hit_t = a.w;
+    w.hit_idx = __float_as_int(b.w);
+    w.p.depth = __float_as_uint(c.w);
+    w.sample = __float_as_uint(e.w);
+    return w;
 }
-RTX_DEV void wf_store_thr(const WfState &S, uint32_t px, const Path &p)
+RTX_DEV void wf_store_ray(const WfState &S, uint32_t slot, const Path &p, float hit_t, int hit_idx)
 {
-    S.thr[0][px] = p.T.x; S.thr[1][px] = p.T.y; S.thr[2][px] = p.T.z;
+    float4 *r = S.rec + 4ull * slot;
+    r[0] = make_float4(p.o.x, p.o.y, p.o.z, hit_t);
+    r[1] = make_float4(p.d.x, p.d.y, p.d.z, __int_as_float(hit_idx));
 }
-RTX_DEV void wf_store_rad(const WfState &S, uint32_t px, const Path &p)
+RTX_DEV void wf_store_thr(const WfState &S, uint32_t slot, const Path &p)
 {
-    S.rad[0][px] = p.L.x; S.rad[1][px] = p.L.y; S.rad[2][px] = p.L.z;
+    S.rec[4ull * slot + 2] = make_float4(p.T.x, p.T.y, p.T.z, __uint_as_float(p.depth));
+}
+RTX_DEV void wf_store_rad(const WfState &S, uint32_t slot, V3 L, uint32_t sample)
+{
+    S.rec[4ull * slot + 3] = make_float4(L.x, L.y, L.z, __uint_as_float(sample));
 }
 // the path of pixel `pixel` is complete: add it to the pixel's sum, move to the next sample
-RTX_DEV bool wf_finish_path(const RenderParams &P, const WfState &S, uint32_t slot, uint32_t pixel, V3 L)
+RTX_DEV bool wf_finish_path(const RenderParams &P, const WfState &S, uint32_t slot, uint32_t pixel, V3 L,
+                            uint32_t sample)
 {
     float *out = P.out_sum + 3ull * pixel;
     out[0] = out[0] + L.x;
     out[1] = out[1] + L.y;
     out[2] = out[2] + L.z;
-    uint32_t s = S.sample[slot] + 1u;
-    S.sample[slot] = s;
-    return s < P.sample_first + P.sample_count;  // more samples to do
+    wf_store_rad(S, slot, v3(0.0f, 0.0f, 0.0f), sample + 1u);
+    return sample + 1u < P.sample_first + P.sample_count;  // more samples to do
 }
 
 // one material's queue: scatter (src/trace.rs:25-68 for that material)
@@ -119,15 +132,13 @@ RTX_DEV void wf_shade(const RenderParams &P, const WfState &S, WfLds &L, const T
             wf_pixel(P, local, px, py);
             const uint32_t pixel = py * P.width + px;
             const uint32_t slot = blockIdx.x * kWfPixelsPerGroup + local;
-            Path p = wf_load_path(S, slot);
-            const bool ended = bounce<STATS, MANY_LIGHTS>(P, tab, p, S.hit_idx[slot], S.hit_t[slot], MATERIAL, pixel,
-                                             S.sample[slot], cnt);
+            WfPath w = wf_load(S, slot);
+            const bool ended = bounce<STATS, MANY_LIGHTS>(P, tab, w.p, w.hit_idx, w.hit_t, MATERIAL, pixel, w.sample, cnt);
             if (ended) {
-                refresh = wf_finish_path(P, S, slot, pixel, p.L);
+                refresh = wf_finish_path(P, S, slot, pixel, w.p.L, w.sample);
             } else {
-                wf_store_ray(S, slot, p);
-                wf_store_thr(S, slot, p);
-                S.depth[slot] = p.depth;
+                wf_store_ray(S, slot, w.p, 0.0f, -1);
+                wf_store_thr(S, slot, w.p);
                 go_on = true;
             }
         }
@@ -174,7 +185,7 @@ __global__ void __launch_bounds__(kWfThreads) k_wavefront(const RenderParams P, 
         const bool valid = wf_pixel(P, local, px, py);
         if (valid) {
             const uint32_t pixel = py * P.width + px;
-            S.sample[blockIdx.x * kWfPixelsPerGroup + local] = P.sample_first;
+            wf_store_rad(S, blockIdx.x * kWfPixelsPerGroup + local, v3(0.0f, 0.0f, 0.0f), P.sample_first);
             P.out_sum[3ull * pixel + 0] = 0.0f;
             P.out_sum[3ull * pixel + 1] = 0.0f;
             P.out_sum[3ull * pixel + 2] = 0.0f;
@@ -207,15 +218,15 @@ __global__ void __launch_bounds__(kWfThreads) k_wavefront(const RenderParams P, 
                     wf_pixel(P, local, px, py);
                     const uint32_t pixel = py * P.width + px;
                     const uint32_t slot = blockIdx.x * kWfPixelsPerGroup + local;
-                    uint4 w = draw_block(P, pixel, S.sample[slot], 0u);
+                    // the finished path left (0, 0, 0 | next sample index) in the radiance record
+                    const uint32_t sample = __float_as_uint(S.rec[4ull * slot + 3].w);
+                    uint4 w = draw_block(P, pixel, sample, 0u);
                     Path p;
                     camera_ray(P, px, P.height - 1u - py, u24(w.x), u24(w.y), p.o, p.d);
                     p.T = v3(1.0f, 1.0f, 1.0f);
-                    p.L = v3(0.0f, 0.0f, 0.0f);
-                    wf_store_ray(S, slot, p);
+                    p.depth = 0u;
+                    wf_store_ray(S, slot, p, 0.0f, -1);
                     wf_store_thr(S, slot, p);
-                    wf_store_rad(S, slot, p);
-                    S.depth[slot] = 0u;
                     cnt.template add<C_SAMPLES>();
                 }
                 wf_push(L, Q_ACTIVE0 + cur, valid, local);
@@ -238,7 +249,8 @@ __global__ void __launch_bounds__(kWfThreads) k_wavefront(const RenderParams P, 
                     wf_pixel(P, local, px, py);
                     const uint32_t pixel = py * P.width + px;
                     const uint32_t slot = blockIdx.x * kWfPixelsPerGroup + local;
-                    Path p = wf_load_path(S, slot);
+                    WfPath w = wf_load(S, slot);
+                    Path &p = w.p;
                     cnt.template add<C_RAYS>();
                     float t;
                     int idx;
@@ -258,11 +270,10 @@ __global__ void __launch_bounds__(kWfThreads) k_wavefront(const RenderParams P, 
                         done = surface_emission(P, tab, p, idx);
                     }
                     if (done) {
-                        refresh = wf_finish_path(P, S, slot, pixel, p.L);
+                        refresh = wf_finish_path(P, S, slot, pixel, p.L, w.sample);
                     } else {
-                        wf_store_rad(S, slot, p);
-                        S.hit_t[slot] = t;
-                        S.hit_idx[slot] = idx;
+                        wf_store_rad(S, slot, p.L, w.sample);
+                        wf_store_ray(S, slot, p, t, idx);
                         material = __float_as_int(tab.mat[3 * idx + 0].w);
                     }
                 }
@@ -301,23 +312,12 @@ static uint32_t wavefront_slots(uint32_t width, uint32_t height)
 
 size_t wavefront_state_bytes(uint32_t width, uint32_t height)
 {
-    // 12 float arrays + depth + sample + hit_t + hit_idx, one entry per slot
-    return (size_t)wavefront_slots(width, height) * 4u * 16u + 256u;
+    return (size_t)wavefront_slots(width, height) * 4u * sizeof(float4);
 }
 
-void wavefront_bind_state(void *block, uint32_t width, uint32_t height, WfState &S)
+void wavefront_bind_state(void *block, uint32_t, uint32_t, WfState &S)
 {
-    const uint32_t n_slots = wavefront_slots(width, height);
-    uint32_t *base = static_cast<uint32_t *>(block);
-    size_t k = 0;
-    auto next = [&]() { uint32_t *p = base + k * (size_t)n_slots; ++k; return p; };
-    for (int i = 0; i < 6; ++i) S.ray[i] = reinterpret_cast<float *>(next());
-    for (int i = 0; i < 3; ++i) S.thr[i] = reinterpret_cast<float *>(next());
-    for (int i = 0; i < 3; ++i) S.rad[i] = reinterpret_cast<float *>(next());
-    S.depth = next();
-    S.sample = next();
-    S.hit_t = reinterpret_cast<float *>(next());
-    S.hit_idx = reinterpret_cast<int32_t *>(next());
+    S.rec = static_cast<float4 *>(block);
 }
 
 template <int SRC, bool STATS, bool MANY_LIGHTS>

@@ -1,0 +1,32 @@
+"""Turns gpurun_out/prof_<workload>_<mode>/ (written by tools/profile.sh) into the summaries kept
+under profiles/<round>/: <workload>_<mode>_kernel_stats.csv, _pmc.json and _bench.json."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+workload, mode, rnd = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "r1")
+src = f"gpurun_out/prof_{workload}_{mode}"
+dst = f"profiles/{rnd}"
+os.makedirs(dst, exist_ok=True)
+key = "wavefront" if mode == "wavefront" else "megakernel"
+out = {}
+for d in "abcd":
+    for f in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if key in r["Kernel_Name"]:
+                out[r["Counter_Name"]] = float(r["Counter_Value"])
+                out["kernel"] = r["Kernel_Name"]
+if "SQ_THREAD_CYCLES_VALU" in out:
+    out["thread_active_fraction"] = out["SQ_THREAD_CYCLES_VALU"] / (64 * out["SQ_ACTIVE_INST_VALU"])
+if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
+    out["hbm_bytes_per_launch"] = (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024
+json.dump(out, open(f"{dst}/{workload}_{mode}_pmc.json", "w"), indent=1, sort_keys=True)
+for f in glob.glob(f"{src}/trace/*/*_kernel_stats.csv"):
+    shutil.copy(f, f"{dst}/{workload}_{mode}_kernel_stats.csv")
+for line in open(f"{src}/trace.log"):
+    if line.startswith("{"):
+        open(f"{dst}/{workload}_{mode}_bench.json", "w").write(line)
+print(json.dumps(out, indent=1, sort_keys=True))
