@@ -119,7 +119,10 @@ def main():
             raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is always created, so the
+    # RCCL path is the one exercised even with a single rank
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     name = args.workload or ("c2" if world == 1 else "c4")
@@ -144,24 +147,24 @@ def main():
         r.render_samples(first, count, buf.data_ptr(), stream)
         if ev:
             ev[1].record()
-        if world > 1:
+        if use_dist:
             dist.all_reduce(buf, op=dist.ReduceOp.SUM)
         r.divide(buf.data_ptr(), n_floats, float(scene.n_samples), stream)
 
     for _ in range(args.warmup):
         step()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -193,7 +196,7 @@ def main():
                     "flops_per_sample": flops_rank / max(1, stats["samples"]),
                     "rays_per_sample": stats["rays"] / max(1, stats["samples"])}
         rays = torch.tensor([stats["rays"]], dtype=torch.float64, device="cuda")
-        if world > 1:
+        if use_dist:
             dist.all_reduce(rays, op=dist.ReduceOp.SUM)
         rays_total = float(rays.item())
 
@@ -219,7 +222,7 @@ def main():
             out["speedup_vs_cpu_1thread"] = value / cb["value"]
         print(json.dumps(out), flush=True)
     r.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
