@@ -141,9 +141,46 @@ int rtx_render(rtx_ctx *ctx, const rtx_scene *scene, float *rgb);
 int rtx_render_samples(rtx_ctx *ctx, uint32_t sample_first, uint32_t sample_count,
                        float *d_sum, void *hip_stream);
 
+/* As rtx_render_samples, but the per-pixel sums CONTINUE from the values already in
+ * d_sum: calls over [0, a) and then [a, b) leave the bits one call over [0, b)
+ * writes.  src/main.rs:23-27 keeps the image a valid mean after every sample step so
+ * the loop can stop anywhere; this is that property for a sum kept on the device. */
+int rtx_accumulate_samples(rtx_ctx *ctx, uint32_t sample_first, uint32_t sample_count,
+                           float *d_sum, void *hip_stream);
+
 /* d_rgb[i] = d_rgb[i] / divisor on the device: turns summed radiance into the
  * mean that src/main.rs:26 maintains. */
 int rtx_divide(rtx_ctx *ctx, float *d_rgb, uint64_t n_floats, float divisor, void *hip_stream);
+
+/* The output stage of src/main.rs:40-41 on the device: for each of n_floats values of
+ * d_sum, x = d_sum[i] / divisor, the ACES curve and saturate (src/image.rs:65-79), gamma
+ * 1/2.2 (src/image.rs:60-63) and the byte conversion of src/image.rs:44 into d_bytes
+ * (DEVICE buffers; d_sum is not modified).  Float operations and their order are the
+ * reference's; powf comes from the device library, so a byte may differ by one from
+ * rtx_host_color_correction + rtx_host_to_bytes where the value sits on a rounding
+ * boundary. */
+int rtx_tonemap_bytes(rtx_ctx *ctx, const float *d_sum, uint64_t n_floats, float divisor,
+                      uint8_t *d_bytes, void *hip_stream);
+
+/* render + color_correction + the byte conversion of write (src/main.rs:38-41) without
+ * the float image leaving the device: bytes = width*height*3 values of the PPM body
+ * (host memory, row 0 = top). */
+int rtx_render_bytes(rtx_ctx *ctx, const rtx_scene *scene, uint8_t *bytes);
+
+/* Progressive rendering on a sum buffer the context owns (stop / checkpoint / resume;
+ * the reference's loop is interruptible after any sample step, src/main.rs:14-28).
+ *   begin: set the scene; start from zero samples (sum = NULL, samples_done = 0) or
+ *          from a saved state (sum = width*height*3 host floats, the sum of samples
+ *          [0, samples_done)).
+ *   step:  render the next sample_count samples onto the sum; returns when done.
+ *   read:  any of rgb_mean (sum / samples, what rtx_render returns), sum (the state to
+ *          save), bytes (tone-mapped, as rtx_render_bytes) and samples_done may be NULL.
+ * After begin + steps totalling n samples, read returns the bits of rtx_render with
+ * n_samples = n, however the steps were cut and wherever a save / resume happened.
+ * rtx_render and rtx_render_bytes on the same context end the progressive render. */
+int rtx_progress_begin(rtx_ctx *ctx, const rtx_scene *scene, const float *sum, uint32_t samples_done);
+int rtx_progress_step(rtx_ctx *ctx, uint32_t sample_count);
+int rtx_progress_read(rtx_ctx *ctx, float *rgb_mean, float *sum, uint8_t *bytes, uint32_t *samples_done);
 
 /* Deterministic primary-visibility pass: one ray through every pixel centre
  * (src/main.rs:19-21 with du = dv = 0.5) and its closest hit (src/trace.rs:102-121).
@@ -168,7 +205,7 @@ const char *rtx_last_error(void);
 
 /* ABI version of this header: bumped on any layout or signature change. */
 uint32_t rtx_abi_version(void);
-#define RTX_ABI_VERSION 1u
+#define RTX_ABI_VERSION 2u
 
 #ifdef __cplusplus
 }

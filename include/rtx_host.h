@@ -43,6 +43,28 @@ void rtx_host_to_bytes(const float *rgb, uint64_t n_floats, uint8_t *out);
  * rgb = width*height*3 floats, row 0 = top. */
 int rtx_host_write_ppm(const char *path, const float *rgb, uint32_t width, uint32_t height);
 
+/* Image::write for values that are bytes already (the body rtx_render_bytes returns). */
+int rtx_host_write_ppm_bytes(const char *path, const uint8_t *bytes, uint32_t width, uint32_t height);
+
+/* Checkpoints of a progressive render (no counterpart in the reference, whose only state is
+ * the image in memory).  File = 64-byte header {magic "RTXCKPT1", width, height,
+ * samples_done, reserved, seed, scene fingerprint, ...zero} + width*height*3 little-endian
+ * floats: the per-pixel sum of samples [0, samples_done).  The save is atomic (temporary
+ * file + rename), so an interrupted run leaves the previous checkpoint intact. */
+typedef struct rtx_host_checkpoint {
+    uint32_t width, height;
+    uint32_t samples_done;
+    uint64_t seed;
+    uint64_t fingerprint; /* rtx_host_scene_fingerprint of the scene being rendered */
+} rtx_host_checkpoint;
+/* FNV-1a over everything that determines a sample's value: image size, depth, background,
+ * camera and every object (n_samples excluded: a resumed run may ask for more). */
+uint64_t rtx_host_scene_fingerprint(const rtx_scene *scene);
+int rtx_host_save_checkpoint(const char *path, const rtx_host_checkpoint *info, const float *sum);
+/* Reads the header into info; when sum is not NULL also the body (capacity_floats must be
+ * at least width*height*3).  RTX_ERR_INVALID_ARG: unreadable, truncated or not a checkpoint. */
+int rtx_host_load_checkpoint(const char *path, rtx_host_checkpoint *info, float *sum, uint64_t capacity_floats);
+
 const char *rtx_host_last_error(void);
 
 #ifdef __cplusplus

@@ -21,7 +21,7 @@ RTX_ERR_NO_SCENE = -4
 RTX_ERR_UNSUPPORTED = -5
 RTX_ERR_NO_MEMORY = -6
 
-RTX_ABI_VERSION = 1
+RTX_ABI_VERSION = 2
 RTX_MAX_LDS_PRIMS = 512
 
 

@@ -46,4 +46,16 @@ int rtx_host_write_ppm(const char *path, const float *rgb, uint32_t width, uint3
     return ok ? RTX_OK : RTX_ERR_INVALID_ARG;
 }
 
+int rtx_host_write_ppm_bytes(const char *path, const uint8_t *bytes, uint32_t width, uint32_t height)
+{
+    if (!path || !bytes) return RTX_ERR_INVALID_ARG;
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return RTX_ERR_INVALID_ARG;
+    const uint64_t n = (uint64_t)width * height * 3u;
+    bool ok = std::fprintf(f, "P6\n%u %u\n255\n", width, height) > 0;
+    ok = ok && (n == 0 || std::fwrite(bytes, 1, n, f) == n);
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? RTX_OK : RTX_ERR_INVALID_ARG;
+}
+
 }  // extern "C"

@@ -72,6 +72,11 @@ struct rtx_ctx {
     // scratch owned by the context
     float *d_image = nullptr;
     size_t d_image_floats = 0;
+    uint8_t *d_bytes = nullptr;   // tone-mapped image
+    size_t d_bytes_size = 0;
+    // progressive rendering: d_image holds the sum of samples [0, progress_done)
+    bool progress_active = false;
+    uint32_t progress_done = 0;
     void *d_wavefront = nullptr;  // path state of the wavefront variant
     size_t d_wavefront_bytes = 0;
     unsigned long long *d_stats = nullptr;
@@ -115,6 +120,20 @@ bool is_identity_pose(const rtx_prim &p)
     if (q[0] != 0u || q[1] != 0u || q[2] != 0u || q[3] != 0x3f800000u) return false;
     for (int k = 0; k < 3; ++k)
         if (!(std::fabs(p.position[k]) < 1e30f)) return false;
+    return true;
+}
+
+// every component of the parameter vector is 2^e with |e| <= 60: dividing by it and multiplying
+// by its (exact) inverse round the same real number (rtx_trace.hpp: div_param)
+bool is_pow2_param(const rtx_prim &p)
+{
+    if (p.kind == RTX_PLANE) return false;
+    for (int k = 0; k < 3; ++k) {
+        uint32_t b;
+        std::memcpy(&b, &p.param[k], 4);
+        const uint32_t e = b >> 23;  // sign bit included: negative values fail the range test
+        if ((b & 0x7fffffu) != 0u || e < 127u - 60u || e > 127u + 60u) return false;
+    }
     return true;
 }
 
@@ -166,7 +185,8 @@ int upload_scene(rtx_ctx *c)
     int32_t *lights = reinterpret_cast<int32_t *>(host.data() + geom_bytes + mat_bytes);
     for (size_t i = 0; i < n; ++i) {
         const rtx_prim &p = c->prims[i];
-        int32_t kind = (int32_t)p.kind | (is_identity_pose(p) ? (rtx::kGeomIdentity << 8) : 0);
+        int32_t kind = (int32_t)p.kind | (is_identity_pose(p) ? (rtx::kGeomIdentity << 8) : 0) |
+                       (is_pow2_param(p) ? (rtx::kGeomPow2 << 8) : 0);
         int32_t material = (int32_t)p.material;
         float kind_bits, mat_bits;
         std::memcpy(&kind_bits, &kind, 4);
@@ -263,6 +283,17 @@ int ensure_image(rtx_ctx *c, size_t floats)
     return RTX_OK;
 }
 
+int ensure_bytes(rtx_ctx *c, size_t n)
+{
+    if (c->d_bytes_size >= n) return RTX_OK;
+    if (c->d_bytes) (void)hipFree(c->d_bytes);
+    c->d_bytes = nullptr;
+    c->d_bytes_size = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_bytes), n));
+    c->d_bytes_size = n;
+    return RTX_OK;
+}
+
 void stats_from_counters(const rtx_ctx *c, const unsigned long long *v, rtx_stats *s)
 {
     std::memset(s, 0, sizeof(*s));
@@ -340,6 +371,7 @@ void rtx_destroy(rtx_ctx *c)
     DeviceGuard g(c->device);
     free_scene(c);
     if (c->d_image) (void)hipFree(c->d_image);
+    if (c->d_bytes) (void)hipFree(c->d_bytes);
     if (c->d_wavefront) (void)hipFree(c->d_wavefront);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
@@ -376,9 +408,10 @@ int rtx_set_scene(rtx_ctx *c, const rtx_scene *s)
     return RTX_OK;
 }
 
-int rtx_render_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream)
+static int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream,
+                        bool accumulate)
 {
-    if (!c || !d_sum) return fail(RTX_ERR_INVALID_ARG, "rtx_render_samples: null argument");
+    if (!c || !d_sum) return fail(RTX_ERR_INVALID_ARG, "render: null argument");
     if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_set_scene has not been called");
     if ((uint64_t)sample_first + sample_count > 0xffffffffull)
         return fail(RTX_ERR_INVALID_ARG, "sample range overflows 32 bits");
@@ -389,6 +422,7 @@ int rtx_render_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count,
     P.sample_first = sample_first;
     P.sample_count = sample_count;
     P.out_sum = d_sum;
+    P.accumulate = accumulate ? 1u : 0u;
     const bool stats = c->opts.collect_stats != 0;
     P.stats = stats ? c->d_stats : nullptr;
     c->stats_valid = false;
@@ -421,6 +455,26 @@ int rtx_render_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count,
     return RTX_OK;
 }
 
+int rtx_render_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream)
+{
+    return render_range(c, sample_first, sample_count, d_sum, hip_stream, false);
+}
+
+int rtx_accumulate_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream)
+{
+    return render_range(c, sample_first, sample_count, d_sum, hip_stream, true);
+}
+
+int rtx_tonemap_bytes(rtx_ctx *c, const float *d_sum, uint64_t n_floats, float divisor, uint8_t *d_bytes,
+                      void *hip_stream)
+{
+    if (!c || !d_sum || !d_bytes) return fail(RTX_ERR_INVALID_ARG, "rtx_tonemap_bytes: null argument");
+    DeviceGuard g(c->device);
+    if (!g.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", c->device);
+    HIP_TRY(rtx::launch_tonemap(d_sum, n_floats, divisor, d_bytes, static_cast<hipStream_t>(hip_stream)));
+    return RTX_OK;
+}
+
 int rtx_divide(rtx_ctx *c, float *d_rgb, uint64_t n_floats, float divisor, void *hip_stream)
 {
     if (!c || !d_rgb) return fail(RTX_ERR_INVALID_ARG, "rtx_divide: null argument");
@@ -439,6 +493,7 @@ int rtx_render(rtx_ctx *c, const rtx_scene *s, float *rgb)
     const size_t floats = (size_t)s->width * s->height * 3u;
     rc = ensure_image(c, floats);
     if (rc != RTX_OK) return rc;
+    c->progress_active = false;
     if (s->n_samples == 0) {
         // src/main.rs:14: zero iterations leave the zero-initialised image (src/image.rs:17)
         std::memset(rgb, 0, floats * sizeof(float));
@@ -449,6 +504,85 @@ int rtx_render(rtx_ctx *c, const rtx_scene *s, float *rgb)
     rc = rtx_divide(c, c->d_image, floats, (float)s->n_samples, nullptr);
     if (rc != RTX_OK) return rc;
     HIP_TRY(hipMemcpy(rgb, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_render_bytes(rtx_ctx *c, const rtx_scene *s, uint8_t *bytes)
+{
+    if (!c || !bytes) return fail(RTX_ERR_INVALID_ARG, "rtx_render_bytes: null argument");
+    int rc = rtx_set_scene(c, s);
+    if (rc != RTX_OK) return rc;
+    DeviceGuard g(c->device);
+    const size_t floats = (size_t)s->width * s->height * 3u;
+    rc = ensure_image(c, floats);
+    if (rc == RTX_OK) rc = ensure_bytes(c, floats);
+    if (rc != RTX_OK) return rc;
+    c->progress_active = false;
+    // zero samples leave the zero image (src/main.rs:14, src/image.rs:17); 0 / 1 keeps it
+    rc = rtx_render_samples(c, 0, s->n_samples, c->d_image, nullptr);
+    if (rc != RTX_OK) return rc;
+    const float divisor = s->n_samples == 0 ? 1.0f : (float)s->n_samples;
+    rc = rtx_tonemap_bytes(c, c->d_image, floats, divisor, c->d_bytes, nullptr);
+    if (rc != RTX_OK) return rc;
+    HIP_TRY(hipMemcpy(bytes, c->d_bytes, floats, hipMemcpyDeviceToHost));
+    return RTX_OK;
+}
+
+int rtx_progress_begin(rtx_ctx *c, const rtx_scene *s, const float *sum, uint32_t samples_done)
+{
+    if (!c) return fail(RTX_ERR_INVALID_ARG, "ctx is null");
+    c->progress_active = false;
+    if (!sum && samples_done != 0)
+        return fail(RTX_ERR_INVALID_ARG, "rtx_progress_begin: %u samples done but no sum to resume from", samples_done);
+    int rc = rtx_set_scene(c, s);
+    if (rc != RTX_OK) return rc;
+    DeviceGuard g(c->device);
+    const size_t floats = (size_t)s->width * s->height * 3u;
+    rc = ensure_image(c, floats);
+    if (rc != RTX_OK) return rc;
+    if (sum) HIP_TRY(hipMemcpy(c->d_image, sum, floats * sizeof(float), hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(c->d_image, 0, floats * sizeof(float)));
+    c->progress_done = samples_done;
+    c->progress_active = true;
+    return RTX_OK;
+}
+
+int rtx_progress_step(rtx_ctx *c, uint32_t sample_count)
+{
+    if (!c) return fail(RTX_ERR_INVALID_ARG, "ctx is null");
+    if (!c->progress_active) return fail(RTX_ERR_NO_SCENE, "rtx_progress_begin has not been called");
+    if ((uint64_t)c->progress_done + sample_count > 0xffffffffull)
+        return fail(RTX_ERR_INVALID_ARG, "sample range overflows 32 bits");
+    DeviceGuard g(c->device);
+    int rc = rtx_accumulate_samples(c, c->progress_done, sample_count, c->d_image, nullptr);
+    if (rc != RTX_OK) { c->progress_active = false; return rc; }
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    c->progress_done += sample_count;
+    return RTX_OK;
+}
+
+int rtx_progress_read(rtx_ctx *c, float *rgb_mean, float *sum, uint8_t *bytes, uint32_t *samples_done)
+{
+    if (!c) return fail(RTX_ERR_INVALID_ARG, "ctx is null");
+    if (!c->progress_active) return fail(RTX_ERR_NO_SCENE, "rtx_progress_begin has not been called");
+    DeviceGuard g(c->device);
+    const size_t floats = (size_t)c->scene.width * c->scene.height * 3u;
+    if (samples_done) *samples_done = c->progress_done;
+    if (sum) HIP_TRY(hipMemcpy(sum, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
+    // the mean of zero samples is the zero image the reference starts from (src/image.rs:17)
+    const float divisor = c->progress_done == 0 ? 1.0f : (float)c->progress_done;
+    if (bytes) {
+        int rc = ensure_bytes(c, floats);
+        if (rc != RTX_OK) return rc;
+        rc = rtx_tonemap_bytes(c, c->d_image, floats, divisor, c->d_bytes, nullptr);
+        if (rc != RTX_OK) return rc;
+        HIP_TRY(hipMemcpy(bytes, c->d_bytes, floats, hipMemcpyDeviceToHost));
+    }
+    if (rgb_mean) {
+        // the sum stays on the device untouched: divide on the host copy, the same IEEE division
+        HIP_TRY(hipMemcpy(rgb_mean, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < floats; ++i) rgb_mean[i] = rgb_mean[i] / divisor;
+    }
     return RTX_OK;
 }
 

@@ -21,7 +21,7 @@ namespace rtx {
 
 enum : int { kPlane = 0, kEllipsoid = 1, kBox = 2 };
 enum : int { kDiffuse = 0, kMetallic = 1, kDielectric = 2 };
-enum : int { kGeomIdentity = 1 };  // Geom::flags
+enum : int { kGeomIdentity = 1, kGeomPow2 = 2 };  // Geom::flags
 
 // event counters kept per lane when statistics are requested
 enum : int {
@@ -54,6 +54,7 @@ struct RenderParams {
     uint32_t rng_const;     // 1: every draw block = const_words
     uint32_t const_words[4];
     float *out_sum;         // width*height*3, row 0 = top
+    uint32_t accumulate;    // 1: the sums continue from the values already in out_sum
     unsigned long long *stats; // C_COUNT counters or nullptr
     BvhView bvh;
 };
@@ -72,6 +73,7 @@ constexpr uint32_t kFewLights = 2;
 hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, hipStream_t stream);
 hipError_t launch_primary(const RenderParams &p, const PrimaryParams &out, int src, hipStream_t stream);
 hipError_t launch_divide(float *d, uint64_t n, float divisor, hipStream_t stream);
+hipError_t launch_tonemap(const float *sum, uint64_t n, float divisor, uint8_t *bytes, hipStream_t stream);
 size_t scene_lds_bytes(uint32_t n_prims, uint32_t n_lights);
 
 }  // namespace rtx

@@ -86,7 +86,9 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
     Counters<STATS> cnt;
     cnt.clear();
     const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
+    float *out = P.out_sum + 3ull * pixel;
     V3 sum = v3(0.0f, 0.0f, 0.0f);
+    if (P.accumulate) sum = v3(out[0], out[1], out[2]);
     Path p;
     uint32_t s = P.sample_first;
     const uint32_t s_end = P.sample_first + P.sample_count;
@@ -123,7 +125,6 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
             fresh = true;
         }
     }
-    float *out = P.out_sum + 3ull * pixel;
     out[0] = sum.x;
     out[1] = sum.y;
     out[2] = sum.z;
@@ -165,6 +166,25 @@ __global__ void __launch_bounds__(256) k_divide(float *d, uint64_t n, float divi
 {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
         d[i] = d[i] / divisor;
+}
+
+// The output stage of src/image.rs:65-79 (ACES curve, saturate), :60-63 (gamma 1/2.2) and :44
+// (byte conversion) applied to sum / divisor, the same float operations in the same order.
+// powf is the device library's, not the host libm's: a byte can differ by one from the host
+// path where 255 * x^(1/2.2) falls within an ulp of a rounding boundary.
+__global__ void __launch_bounds__(256) k_tonemap(const float *sum, uint64_t n, float divisor, uint8_t *bytes)
+{
+    const float a = 2.51f, b = 0.03f, c = 2.43f, d = 0.59f, e = 0.14f;
+    const float inv_gamma = 1.0f / 2.2f;
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float x = sum[i] / divisor;
+        const float up = x * (a * x + b);
+        const float down = x * (c * x + d) + e;
+        float y = up / down;
+        y = y < 0.0f ? 0.0f : (y > 1.0f ? 1.0f : y);
+        const float v = roundf(255.0f * powf(y, inv_gamma));
+        bytes[i] = (v != v) ? 0 : (v <= 0.0f ? 0 : (v >= 255.0f ? 255 : (uint8_t)v));
+    }
 }
 
 static dim3 tile_grid(const RenderParams &p)
@@ -213,6 +233,15 @@ hipError_t launch_divide(float *d, uint64_t n, float divisor, hipStream_t stream
     if (blocks > 2048u) blocks = 2048u;
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(k_divide, dim3((uint32_t)blocks), dim3(256), 0, stream, d, n, divisor);
+    return hipGetLastError();
+}
+
+hipError_t launch_tonemap(const float *sum, uint64_t n, float divisor, uint8_t *bytes, hipStream_t stream)
+{
+    uint64_t blocks = (n + 255u) / 256u;
+    if (blocks > 4096u) blocks = 4096u;
+    if (blocks == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_tonemap, dim3((uint32_t)blocks), dim3(256), 0, stream, sum, n, divisor, bytes);
     return hipGetLastError();
 }
 

@@ -48,7 +48,8 @@ struct Geom {
     float4 rot;
     V3 pos;
     int kind;
-    int flags;   // kGeomIdentity: rotation is exactly (+0, +0, +0, 1) and the position is tame
+    int flags;   // kGeomIdentity: rotation is exactly (+0, +0, +0, 1) and the position is tame;
+                 // kGeomPow2: every component of param is a positive power of two
     V3 param;
 };
 RTX_DEV Geom load_geom(const float4 *g, uint32_t i)
@@ -107,10 +108,25 @@ RTX_DEV bool plane_t(V3 n, const LocalRay &r, float &t)
     t = -dot(r.o, n) / dot(r.d, n);
     return !(t < 0.0f); // t = 0, -0 and NaN pass, as in the reference
 }
-RTX_DEV bool ellipsoid_t(V3 rad, const LocalRay &r, float &t)
+// 1 / p for p = 2^e: the exponent field mirrored about the bias
+RTX_DEV V3 pow2_inverse(V3 p)
 {
-    V3 u = cdiv(r.o, rad);
-    V3 v = cdiv(r.d, rad);
+    return v3(__int_as_float(0x7f000000 - __float_as_int(p.x)), __int_as_float(0x7f000000 - __float_as_int(p.y)),
+              __int_as_float(0x7f000000 - __float_as_int(p.z)));
+}
+// x / p for the object's parameter vector.  When every component of p is a power of two
+// (kGeomPow2, set at upload) 1 / p is exact, and x * (1 / p) and x / p are the same real number
+// rounded once: identical bits for every x, subnormal results and non-finite x included.
+// `pow2` must be wave-uniform; the division costs about ten instructions, the product one.
+RTX_DEV V3 div_param(V3 x, V3 p, bool pow2)
+{
+    if (pow2) return cmul(x, pow2_inverse(p));
+    return cdiv(x, p);
+}
+RTX_DEV bool ellipsoid_t(V3 rad, const LocalRay &r, float &t, bool pow2)
+{
+    V3 u = div_param(r.o, rad, pow2);
+    V3 v = div_param(r.d, rad, pow2);
     float a = len2(v);
     float b = dot(u, v);
     float c = len2(u) - 1.0f;
@@ -136,10 +152,14 @@ RTX_DEV bool box_t(V3 s, const LocalRay &r, float &t)
     if (t2 >= 0.0f) { t = t2; return true; }
     return false;
 }
+// `kind` may carry kGeomPow2 << 8 (wave-uniform callers only): an ellipsoid whose radii are
+// powers of two is one more case of the dispatch, so other objects pay nothing for it.
+constexpr int kEllipsoidPow2 = kEllipsoid | (kGeomPow2 << 8);
 RTX_DEV bool figure_t(int kind, V3 param, const LocalRay &r, float &t)
 {
     if (kind == kPlane) return plane_t(param, r, t);
-    if (kind == kEllipsoid) return ellipsoid_t(param, r, t);
+    if (kind == kEllipsoid) return ellipsoid_t(param, r, t, false);
+    if (kind == kEllipsoidPow2) return ellipsoid_t(param, r, t, true);
     return box_t(param, r, t);
 }
 // Local (unnormalised) normal at distance t.
@@ -193,7 +213,8 @@ RTX_DEV int closest_hit_scan(const Table &tab, V3 o, V3 d, float &best_t)
             lr = to_local_identity(g, o, d);
         else
             lr = to_local(g, o, d);
-        int kind = UNIFORM_KIND ? __builtin_amdgcn_readfirstlane(g.kind) : g.kind;
+        int kind = g.kind;
+        if (UNIFORM_KIND) kind = __builtin_amdgcn_readfirstlane(g.kind | ((g.flags & kGeomPow2) << 8));
         float t;
         bool hit = figure_t(kind, g.param, lr, t);
         // src/trace.rs:113-119 with max_dist = +inf drops NaN and +inf distances
@@ -231,17 +252,20 @@ RTX_DEV Hit finish_hit(const Table &tab, int idx, V3 o, V3 d, float t, bool want
 template <bool UNIFORM>
 RTX_DEV bool light_intersect_cos(const Geom &g, V3 o, V3 d, float &t, float &cosv)
 {
-    bool ident = false;
-    if constexpr (UNIFORM)
-        ident = (__builtin_amdgcn_readfirstlane(g.flags) & kGeomIdentity) && __ballot(!ray_is_plain(o, d)) == 0ull;
+    bool ident = false, pow2 = false;
+    if constexpr (UNIFORM) {
+        const int flags = __builtin_amdgcn_readfirstlane(g.flags);
+        ident = (flags & kGeomIdentity) && __ballot(!ray_is_plain(o, d)) == 0ull;
+        pow2 = (flags & kGeomPow2) != 0;
+    }
     LocalRay lr = ident ? to_local_identity(g, o, d) : to_local(g, o, d);
-    if (!figure_t(g.kind, g.param, lr, t)) return false;
+    if (!figure_t(g.kind | (pow2 ? kGeomPow2 << 8 : 0), g.param, lr, t)) return false;
     if (ident && __builtin_amdgcn_readfirstlane(g.kind) == kBox) {
         // Axis-aligned box: the local normal is v * e_k (k = first axis of largest |.|, the
         // other two components are +0).  The identity rotation returns it unchanged, and
         // normalising it gives exactly +-e_k: sqrt(fl(v*v)) = |v| in binary floating point when
         // v*v neither overflows nor underflows, and v / |v| = +-1.  Hence |n . d| = |d_k|.
-        V3 q = cdiv(lr.o + lr.d * t, g.param);
+        V3 q = div_param(lr.o + lr.d * t, g.param, pow2);
         float ax = fabsf(q.x), ay = fabsf(q.y), az = fabsf(q.z);
         int k = 0;
         float vm = ax;

@@ -186,9 +186,11 @@ __global__ void __launch_bounds__(kWfThreads) k_wavefront(const RenderParams P, 
         if (valid) {
             const uint32_t pixel = py * P.width + px;
             wf_store_rad(S, blockIdx.x * kWfPixelsPerGroup + local, v3(0.0f, 0.0f, 0.0f), P.sample_first);
-            P.out_sum[3ull * pixel + 0] = 0.0f;
-            P.out_sum[3ull * pixel + 1] = 0.0f;
-            P.out_sum[3ull * pixel + 2] = 0.0f;
+            if (!P.accumulate) {
+                P.out_sum[3ull * pixel + 0] = 0.0f;
+                P.out_sum[3ull * pixel + 1] = 0.0f;
+                P.out_sum[3ull * pixel + 2] = 0.0f;
+            }
         }
         wf_push(L, Q_FRESH0, valid && P.sample_count > 0u, local);
     }

@@ -20,6 +20,11 @@ class rtx_host_scene(C.Structure):
     _fields_ = [("scene", _abi.rtx_scene), ("prims", C.POINTER(_abi.rtx_prim)), ("fov_x", C.c_float)]
 
 
+class rtx_host_checkpoint(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples_done", C.c_uint32),
+                ("seed", C.c_uint64), ("fingerprint", C.c_uint64)]
+
+
 SYMBOLS = {
     "rtx_host_parse_file": (C.c_int, [C.c_char_p, C.POINTER(rtx_host_scene)]),
     "rtx_host_parse_text": (C.c_int, [C.c_char_p, C.POINTER(rtx_host_scene)]),
@@ -27,6 +32,10 @@ SYMBOLS = {
     "rtx_host_color_correction": (None, [_FP, C.c_uint64]),
     "rtx_host_to_bytes": (None, [_FP, C.c_uint64, C.POINTER(C.c_uint8)]),
     "rtx_host_write_ppm": (C.c_int, [C.c_char_p, _FP, C.c_uint32, C.c_uint32]),
+    "rtx_host_write_ppm_bytes": (C.c_int, [C.c_char_p, C.POINTER(C.c_uint8), C.c_uint32, C.c_uint32]),
+    "rtx_host_scene_fingerprint": (C.c_uint64, [C.POINTER(_abi.rtx_scene)]),
+    "rtx_host_save_checkpoint": (C.c_int, [C.c_char_p, C.POINTER(rtx_host_checkpoint), _FP]),
+    "rtx_host_load_checkpoint": (C.c_int, [C.c_char_p, C.POINTER(rtx_host_checkpoint), _FP, C.c_uint64]),
     "rtx_host_last_error": (C.c_char_p, []),
 }
 _lib = None
@@ -108,3 +117,40 @@ def write_ppm(path: str, rgb: np.ndarray):
     rc = load_library().rtx_host_write_ppm(os.fsencode(path), a.ctypes.data_as(_FP), w, h)
     if rc != 0:
         raise OSError(f"cannot write {path}")
+
+
+def write_ppm_bytes(path: str, data: np.ndarray):
+    """Image::write for an image that is bytes already: uint8 (height, width, 3)."""
+    a = np.ascontiguousarray(data, dtype=np.uint8)
+    rc = load_library().rtx_host_write_ppm_bytes(os.fsencode(path), a.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                 a.shape[1], a.shape[0])
+    if rc != 0:
+        raise OSError(f"cannot write {path}")
+
+
+def scene_fingerprint(scene: Scene) -> int:
+    s, keep = scene.to_ctypes()
+    return int(load_library().rtx_host_scene_fingerprint(C.byref(s)))
+
+
+def save_checkpoint(path: str, scene: Scene, seed: int, samples_done: int, sum: np.ndarray):
+    """State of a progressive render: the per-pixel sum of samples [0, samples_done)."""
+    a = np.ascontiguousarray(sum, dtype=np.float32)
+    if a.size != scene.width * scene.height * 3:
+        raise ValueError("sum does not have width*height*3 values")
+    info = rtx_host_checkpoint(scene.width, scene.height, samples_done, seed, scene_fingerprint(scene))
+    if load_library().rtx_host_save_checkpoint(os.fsencode(path), C.byref(info), a.ctypes.data_as(_FP)) != 0:
+        raise OSError(f"cannot write {path}")
+
+
+def load_checkpoint(path: str):
+    """Returns (info dict, sum float32 (height, width, 3)); raises OSError if it is not a checkpoint."""
+    lib = load_library()
+    info = rtx_host_checkpoint()
+    if lib.rtx_host_load_checkpoint(os.fsencode(path), C.byref(info), None, 0) != 0:
+        raise OSError(f"{path} is not a checkpoint")
+    out = np.empty((info.height, info.width, 3), dtype=np.float32)
+    if lib.rtx_host_load_checkpoint(os.fsencode(path), C.byref(info), out.ctypes.data_as(_FP), out.size) != 0:
+        raise OSError(f"{path} is truncated or has trailing data")
+    d = {k: getattr(info, k) for k, _ in rtx_host_checkpoint._fields_}
+    return d, out

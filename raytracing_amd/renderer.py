@@ -28,6 +28,12 @@ SYMBOLS = {
     "rtx_set_scene": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene)]),
     "rtx_render": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene), _FP]),
     "rtx_render_samples": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "rtx_accumulate_samples": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "rtx_tonemap_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p]),
+    "rtx_render_bytes": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene), C.POINTER(C.c_uint8)]),
+    "rtx_progress_begin": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene), _FP, C.c_uint32]),
+    "rtx_progress_step": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "rtx_progress_read": (C.c_int, [C.c_void_p, _FP, _FP, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32)]),
     "rtx_divide": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p]),
     "rtx_primary": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene), C.POINTER(C.c_int32), _FP, _FP,
                               C.POINTER(C.c_uint8)]),
@@ -136,6 +142,54 @@ class Renderer:
         """Sum of samples [first, first+count) into a device buffer (raw pointer)."""
         _check(self._lib.rtx_render_samples(self._ctx, sample_first, sample_count,
                                             C.c_void_p(d_sum_ptr), C.c_void_p(stream)))
+
+    def accumulate_samples(self, sample_first: int, sample_count: int, d_sum_ptr: int, stream: int = 0):
+        """As render_samples, continuing the sums already in the device buffer."""
+        _check(self._lib.rtx_accumulate_samples(self._ctx, sample_first, sample_count,
+                                                C.c_void_p(d_sum_ptr), C.c_void_p(stream)))
+
+    def tonemap_bytes(self, d_sum_ptr: int, n_floats: int, divisor: float, d_bytes_ptr: int, stream: int = 0):
+        """ACES + gamma + byte conversion of sum / divisor, device buffer to device buffer."""
+        _check(self._lib.rtx_tonemap_bytes(self._ctx, C.c_void_p(d_sum_ptr), n_floats, divisor,
+                                           C.c_void_p(d_bytes_ptr), C.c_void_p(stream)))
+
+    def render_bytes(self, scene: Scene) -> np.ndarray:
+        """render + color_correction + byte conversion on the device: uint8 (height, width, 3)."""
+        s, keep = scene.to_ctypes()
+        out = np.empty((scene.height, scene.width, 3), dtype=np.uint8)
+        _check(self._lib.rtx_render_bytes(self._ctx, C.byref(s), out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        self._scene = scene
+        return out
+
+    # -- progressive rendering (stop / checkpoint / resume) ---------------
+    def progress_begin(self, scene: Scene, sum: Optional[np.ndarray] = None, samples_done: int = 0):
+        s, keep = scene.to_ctypes()
+        ptr = None
+        if sum is not None:
+            sum = np.ascontiguousarray(sum, dtype=np.float32)
+            if sum.size != scene.width * scene.height * 3:
+                raise ValueError("sum does not have width*height*3 values")
+            ptr = sum.ctypes.data_as(_FP)
+        _check(self._lib.rtx_progress_begin(self._ctx, C.byref(s), ptr, samples_done))
+        self._scene = scene
+
+    def progress_step(self, sample_count: int):
+        _check(self._lib.rtx_progress_step(self._ctx, sample_count))
+
+    def progress_read(self, what: str = "mean"):
+        """what = 'mean' | 'sum' (float32 (h, w, 3)) | 'bytes' (uint8); returns (array, samples_done)."""
+        sc = self._scene
+        done = C.c_uint32()
+        shape = (sc.height, sc.width, 3)
+        if what == "bytes":
+            out = np.empty(shape, dtype=np.uint8)
+            _check(self._lib.rtx_progress_read(self._ctx, None, None, out.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                               C.byref(done)))
+        else:
+            out = np.empty(shape, dtype=np.float32)
+            args = (out.ctypes.data_as(_FP), None) if what == "mean" else (None, out.ctypes.data_as(_FP))
+            _check(self._lib.rtx_progress_read(self._ctx, args[0], args[1], None, C.byref(done)))
+        return out, done.value
 
     def divide(self, d_ptr: int, n_floats: int, divisor: float, stream: int = 0):
         _check(self._lib.rtx_divide(self._ctx, C.c_void_p(d_ptr), n_floats, divisor, C.c_void_p(stream)))

@@ -396,3 +396,57 @@ def test_many_lights_of_both_kinds(oracle):
         assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
         gstats.pop("bvh_node_tests")
         assert gstats == wstats
+
+
+# ------------------------------------------------- progressive rendering, device tone map
+@pytest.mark.parametrize("mode", [_abi.MODE_MEGAKERNEL, _abi.MODE_WAVEFRONT])
+def test_progressive_steps_equal_the_one_shot_render(mode):
+    """Sums continue across calls: any cut of the sample range, with a save / restore of the
+    state in the middle, leaves the bits of the single call."""
+    sc = reference_scene(width=72, height=40, n_samples=13)
+    with Renderer(seed=8, mode=mode) as r:
+        want = r.render(sc)
+        r.progress_begin(sc)
+        assert r.progress_read("mean")[1] == 0 and not r.progress_read("mean")[0].any()
+        for n in (1, 5, 0, 2):
+            r.progress_step(n)
+        state, done = r.progress_read("sum")
+        assert done == 8
+        part = r.render(sc.replace(n_samples=8))          # ends the progressive render
+        with pytest.raises(RtxError):
+            r.progress_step(1)
+    assert np.array_equal((state / np.float32(8)).view(np.uint32), part.view(np.uint32))
+    with Renderer(seed=8, mode=mode) as r:                 # a new context, as after a restart
+        r.progress_begin(sc, sum=state, samples_done=8)
+        r.progress_step(5)
+        got, done = r.progress_read("mean")
+        assert done == 13
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+        with pytest.raises(RtxError):
+            r.progress_begin(sc, sum=None, samples_done=3)
+
+
+def test_device_tonemap_matches_the_host_output_stage():
+    from raytracing_amd import host
+    sc = reference_scene(width=160, height=120, n_samples=6)
+    with Renderer(seed=2) as r:
+        linear = r.render(sc)
+        got = r.render_bytes(sc)
+        r.progress_begin(sc)
+        r.progress_step(6)
+        again, _ = r.progress_read("bytes")
+    want = host.to_bytes(host.color_correction(linear))
+    assert got.shape == want.shape == (120, 160, 3) and np.array_equal(got, again)
+    diff = np.abs(got.astype(int) - want.astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-4
+    assert (got[want == 245] == 245).all() and (want == 245).any()      # the light's pixels
+    # special values through the device buffers: NaN -> 0, inf -> NaN (inf / inf) -> 0, negatives
+    import torch
+    x = torch.tensor([0.0, 2.0, 4.0, float("inf"), float("nan"), -0.5, 1e-8, 1e6], dtype=torch.float32, device="cuda")
+    out = torch.empty(x.numel(), dtype=torch.uint8, device="cuda")
+    with Renderer() as r:
+        r.tonemap_bytes(x.data_ptr(), x.numel(), 2.0, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    want = host.to_bytes(host.color_correction((x.cpu().numpy() / np.float32(2.0))))
+    assert np.abs(out.cpu().numpy().astype(int) - want.astype(int)).max() <= 1
+    assert out.cpu().numpy()[[0, 3, 4]].tolist() == want[[0, 3, 4]].tolist()

@@ -167,6 +167,35 @@ def test_ppm_writer(tmp_path, oracle):
     assert np.array_equal(np.frombuffer(data[len(header):], dtype=np.uint8), oracle.to_bytes(img).reshape(-1))
 
 
+def test_checkpoint_files(tmp_path):
+    sc = reference_scene(width=6, height=5, n_samples=9)
+    rng = np.random.default_rng(2)
+    total = rng.uniform(0, 50, size=(5, 6, 3)).astype(np.float32)
+    total[0, 0] = (np.inf, -0.0, 1e-42)
+    path = str(tmp_path / "state.ckpt")
+    host.save_checkpoint(path, sc, seed=(1 << 40) + 7, samples_done=4, sum=total)
+    assert os.path.getsize(path) == 64 + total.nbytes and not os.path.exists(path + ".tmp")
+    info, got = host.load_checkpoint(path)
+    assert info == {"width": 6, "height": 5, "samples_done": 4, "seed": (1 << 40) + 7,
+                    "fingerprint": host.scene_fingerprint(sc)}
+    assert np.array_equal(got.view(np.uint32), total.view(np.uint32))
+    # the fingerprint covers what decides a sample's value and nothing else
+    fp = host.scene_fingerprint(sc)
+    assert host.scene_fingerprint(sc.replace(n_samples=100)) == fp
+    assert host.scene_fingerprint(sc.replace(ray_depth=7)) != fp
+    assert host.scene_fingerprint(sc.replace(width=5, height=6)) != fp
+    assert host.scene_fingerprint(sc.replace(prims=sc.prims[:-1])) != fp
+    assert host.scene_fingerprint(sc.replace(prims=sc.prims[:-2] + sc.prims[:-3:-1])) != fp   # order matters
+    # truncated, extended and foreign files are refused
+    blob = open(path, "rb").read()
+    for bad in (blob[:-4], blob + b"\0", b"P6\n6 5\n255\n" + blob[13:], blob[:40]):
+        open(path, "wb").write(bad)
+        with pytest.raises(OSError):
+            host.load_checkpoint(path)
+    with pytest.raises(OSError):
+        host.load_checkpoint(str(tmp_path / "missing.ckpt"))
+
+
 def test_host_library_exports_every_declared_symbol():
     import re
     text = open(os.path.join(ROOT, "include", "rtx_host.h")).read()
@@ -194,3 +223,31 @@ def test_cli_renders_the_sample_scene(tmp_path, oracle):
     want = oracle.to_bytes(oracle.color_correction(oracle.render(sc, seed=3, order=oracle.ORDER_REFERENCE)))
     assert np.abs(got.astype(int) - want.astype(int)).max() <= 1
     assert (got != want).mean() < 0.01
+
+
+@pytest.mark.gpu
+def test_cli_checkpoint_resume_and_device_tonemap(tmp_path):
+    """A render that is stopped, resumed from its checkpoint and cut into uneven steps writes
+    the same file as the one-shot render; the device tone map differs from the host's by at
+    most one in a byte."""
+    scene_path = tmp_path / "scene.txt"
+    scene_path.write_text(SAMPLE)
+    cli = os.path.join(ROOT, "raytracing_amd", "rtx_cli")
+    common = ["--size", "80", "60", "--spp", "11", "--seed", "5"]
+    one_shot, resumed, on_device = (str(tmp_path / n) for n in ("a.ppm", "b.ppm", "c.ppm"))
+    ckpt = str(tmp_path / "state.ckpt")
+    subprocess.check_call([cli, str(scene_path), one_shot] + common)
+    rc = subprocess.call([cli, str(scene_path), resumed, "--chunk", "3", "--checkpoint", ckpt, "--stop-after", "7"] + common)
+    assert rc == 3 and not os.path.exists(resumed)
+    info, _ = host.load_checkpoint(ckpt)
+    assert info["samples_done"] == 7
+    # another seed is another render: the checkpoint is refused, not silently mixed in
+    assert subprocess.call([cli, str(scene_path), resumed, "--checkpoint", ckpt, "--size", "80", "60",
+                            "--spp", "11", "--seed", "6"], stderr=subprocess.DEVNULL) == 1
+    subprocess.check_call([cli, str(scene_path), resumed, "--chunk", "2", "--checkpoint", ckpt, "--mode", "wavefront"] + common)
+    assert host.load_checkpoint(ckpt)[0]["samples_done"] == 11
+    assert open(one_shot, "rb").read() == open(resumed, "rb").read()
+    subprocess.check_call([cli, str(scene_path), on_device, "--device-tonemap", "--chunk", "4"] + common)
+    a = np.frombuffer(open(one_shot, "rb").read(), dtype=np.uint8)
+    c = np.frombuffer(open(on_device, "rb").read(), dtype=np.uint8)
+    assert a.size == c.size and np.abs(a.astype(int) - c.astype(int)).max() <= 1 and (a != c).mean() < 1e-3
