@@ -74,7 +74,7 @@ typedef enum {
     RTX_MODE_WAVEFRONT = 1   /* staged kernels over compacted ray queues */
 } rtx_mode;
 typedef enum {
-    RTX_ACCEL_AUTO = 0,      /* brute force up to RTX_MAX_LDS_PRIMS objects, BVH above */
+    RTX_ACCEL_AUTO = 0,      /* linear scan up to RTX_AUTO_BRUTE_MAX ellipsoids + boxes, BVH above */
     RTX_ACCEL_BRUTE_LDS = 1, /* linear scan, object table staged in LDS */
     RTX_ACCEL_BRUTE_SCALAR = 2, /* linear scan, object table read through the scalar cache */
     RTX_ACCEL_BVH = 3        /* host-built BVH over ellipsoids and boxes + plane list */
@@ -84,7 +84,8 @@ typedef enum {
     RTX_RNG_CONST = 1   /* every draw block returns const_words (zero-randomness shading) */
 } rtx_rng;
 
-#define RTX_MAX_LDS_PRIMS 512u
+#define RTX_MAX_LDS_PRIMS 512u   /* largest object table RTX_ACCEL_BRUTE_LDS accepts */
+#define RTX_AUTO_BRUTE_MAX 6u    /* RTX_ACCEL_AUTO: most non-plane objects the linear scan is chosen for */
 
 typedef struct rtx_opts {
     uint64_t seed;

@@ -104,7 +104,7 @@ def test_zero_randomness_shading(oracle, words):
 def test_event_counters_match_oracle(oracle):
     sc = dielectric_scene(width=64, height=48, n_samples=3, ray_depth=8)
     _, want = oracle.render(sc, seed=2, order=oracle.ORDER_FORWARD, want_stats=True)
-    with Renderer(seed=2, collect_stats=True) as r:
+    with Renderer(seed=2, collect_stats=True, accel=_abi.ACCEL_BRUTE_LDS) as r:
         r.render(sc)
         got = r.stats()
     assert got.pop("bvh_node_tests") == 0
@@ -235,7 +235,12 @@ def test_bvh_on_the_reference_scene_and_auto_selection(oracle):
     with Renderer(seed=8, accel=_abi.ACCEL_BVH) as r:
         got = r.render(sc)
     assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
-    # AUTO: more than RTX_MAX_LDS_PRIMS objects -> BVH
+    # AUTO: the scan for a handful of ellipsoids and boxes (the reference scene has 3), else BVH
+    with Renderer(seed=8, collect_stats=True) as r:
+        r.render(sc)
+        assert r.stats()["bvh_node_tests"] == 0
+        r.render(dielectric_scene(width=32, height=32, n_samples=1, ray_depth=4))
+        assert r.stats()["bvh_node_tests"] > 0
     big = synthetic_scene(n_prims=600, seed=3, width=32, height=32, n_samples=1, ray_depth=3)
     want = oracle.render(big, seed=8, order=oracle.ORDER_FORWARD)
     with Renderer(seed=8, accel=_abi.ACCEL_AUTO, collect_stats=True) as r:
@@ -290,12 +295,17 @@ def test_wavefront_matches_oracle_bitwise(oracle, accel):
 def test_wavefront_dielectric_scene_and_counters(oracle):
     sc = dielectric_scene(width=72, height=40, n_samples=3, ray_depth=16)
     want, wstats = oracle.render(sc, seed=13, order=oracle.ORDER_FORWARD, want_stats=True)
-    with Renderer(seed=13, mode=_abi.MODE_WAVEFRONT, collect_stats=True) as r:
-        got = r.render(sc)
-        gstats = r.stats()
-    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
-    gstats.pop("bvh_node_tests")
-    assert gstats == wstats
+    for accel in (_abi.ACCEL_BRUTE_LDS, _abi.ACCEL_AUTO):       # AUTO traverses the BVH here
+        with Renderer(seed=13, mode=_abi.MODE_WAVEFRONT, collect_stats=True, accel=accel) as r:
+            got = r.render(sc)
+            gstats = r.stats()
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+        nodes = gstats.pop("bvh_node_tests")
+        if accel == _abi.ACCEL_AUTO:
+            # the traversal tests fewer objects than the scan; every other event is the same
+            assert nodes > 0 and sum(gstats["prim_tests"]) < sum(wstats["prim_tests"])
+            gstats["prim_tests"] = wstats["prim_tests"]
+        assert gstats == wstats
 
 
 def test_wavefront_ragged_sizes_ranges_and_empty(oracle):
@@ -389,7 +399,7 @@ def test_many_lights_of_both_kinds(oracle):
     sc = sc.replace(prims=sc.prims + lights)
     want, wstats = oracle.render(sc, seed=6, order=oracle.ORDER_FORWARD, want_stats=True)
     for mode in (_abi.MODE_MEGAKERNEL, _abi.MODE_WAVEFRONT):
-        with Renderer(seed=6, mode=mode, collect_stats=True) as r:
+        with Renderer(seed=6, mode=mode, collect_stats=True, accel=_abi.ACCEL_BRUTE_LDS) as r:
             got = r.render(sc)
             gstats = r.stats()
             assert r.lights() == [5, 8, 9, 10, 11, 12]
