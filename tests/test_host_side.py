@@ -251,3 +251,11 @@ def test_cli_checkpoint_resume_and_device_tonemap(tmp_path):
     a = np.frombuffer(open(one_shot, "rb").read(), dtype=np.uint8)
     c = np.frombuffer(open(on_device, "rb").read(), dtype=np.uint8)
     assert a.size == c.size and np.abs(a.astype(int) - c.astype(int)).max() <= 1 and (a != c).mean() < 1e-3
+
+
+def test_host_sources_are_clean_under_sanitizers():
+    """AddressSanitizer + UBSan over the parser, tone map, PPM and checkpoint code on valid,
+    invalid and mangled inputs (tools/host_sanitize.sh; host code only)."""
+    out = subprocess.run([os.path.join(ROOT, "tools", "host_sanitize.sh")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.startswith("clean:")
