@@ -175,7 +175,7 @@ int upload_scene(rtx_ctx *c)
     rtx::BvhHost bvh;
     const bool want_bvh = c->src == rtx::kSrcBvh;
     if (want_bvh) rtx::build_bvh(c->prims.data(), (uint32_t)n, bvh);
-    const size_t node_bytes = align16(bvh.nodes.size() * sizeof(float4));
+    const size_t node_bytes = align16(bvh.nodes.size() * sizeof(uint4));
     const size_t plane_bytes = align16(bvh.planes.size() * sizeof(int32_t));
 
     const size_t total = geom_bytes + mat_bytes + light_bytes + lbound_bytes + node_bytes + plane_bytes + 16;
@@ -230,7 +230,7 @@ int upload_scene(rtx_ctx *c)
     }
     size_t off_nodes = off_lbound + lbound_bytes;
     size_t off_planes = off_nodes + node_bytes;
-    if (!bvh.nodes.empty()) std::memcpy(host.data() + off_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(float4));
+    if (!bvh.nodes.empty()) std::memcpy(host.data() + off_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(uint4));
     if (!bvh.planes.empty())
         std::memcpy(host.data() + off_planes, bvh.planes.data(), bvh.planes.size() * sizeof(int32_t));
 
@@ -265,9 +265,11 @@ int upload_scene(rtx_ctx *c)
     P.seed_hi = (uint32_t)(c->opts.seed >> 32);
     P.rng_const = c->opts.rng_mode == RTX_RNG_CONST ? 1u : 0u;
     std::memcpy(P.const_words, c->opts.const_words, sizeof(P.const_words));
-    P.bvh.nodes = reinterpret_cast<const float4 *>(base + off_nodes);
+    P.bvh.nodes = reinterpret_cast<const uint4 *>(base + off_nodes);
+    std::memcpy(P.bvh.grid_base, bvh.grid_base, sizeof(P.bvh.grid_base));
+    std::memcpy(P.bvh.grid_inv_step, bvh.grid_inv_step, sizeof(P.bvh.grid_inv_step));
     P.bvh.planes = reinterpret_cast<const int32_t *>(base + off_planes);
-    P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / 4);
+    P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / 2);
     P.bvh.n_planes = (uint32_t)bvh.planes.size();
     return RTX_OK;
 }

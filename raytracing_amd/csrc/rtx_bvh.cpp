@@ -191,9 +191,20 @@ struct Builder {
     }
 };
 
-float round_down(double v) { float f = (float)v; return (double)f > v ? std::nextafterf(f, -INFINITY) : f; }
-float round_up(double v) { float f = (float)v; return (double)f < v ? std::nextafterf(f, INFINITY) : f; }
-float int_bits(int32_t v) { float f; std::memcpy(&f, &v, 4); return f; }
+// Grid coordinate of world coordinate x, rounded outwards with one unit to spare: the
+// traversal moves the ray onto the grid in f32 (error far below one unit for origins within
+// kBvhFarOrigin units of the grid, see rtx_bvh_traverse.hpp), so a ray that enters the true
+// box always enters the stored one.
+uint32_t grid_lo(double x, double base, double inv_step)
+{
+    double g = std::floor((x - base) * inv_step) - 1.0;
+    return (uint32_t)std::min((double)kBvhGridMax, std::max(0.0, g));
+}
+uint32_t grid_hi(double x, double base, double inv_step)
+{
+    double g = std::ceil((x - base) * inv_step) + 1.0;
+    return (uint32_t)std::min((double)kBvhGridMax, std::max(0.0, g));
+}
 
 }  // namespace
 
@@ -238,21 +249,41 @@ void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
         for (int c = 0; c < 2; ++c)
             if (bld.nodes[(size_t)i].ref[c] >= 0) q.push(bld.nodes[(size_t)i].ref[c]);
     }
-    out.nodes.resize(order.size() * 4);
+    // the grid: all boxes, two units of slack at either end so that the outward rounding
+    // never has to clamp
+    Box3 all;
+    all.clear();
+    for (const Ref &r : bld.refs) all.grow(r.box);
+    double base[3], inv_step[3];
+    for (int a = 0; a < 3; ++a) {
+        double ext = std::max(all.hi[a] - all.lo[a], 1e-30);
+        float step = (float)(ext / (double)(kBvhGridMax - 8));
+        float fbase = (float)(all.lo[a] - 4.0 * (double)step);
+        // f32 values are what the device sees; make sure they still cover the range
+        while ((all.hi[a] - (double)fbase) / (double)step > (double)(kBvhGridMax - 3)) step = std::nextafterf(step, INFINITY);
+        float finv = 1.0f / step;
+        out.grid_base[a] = fbase;
+        out.grid_inv_step[a] = finv;
+        base[a] = (double)fbase;
+        inv_step[a] = (double)finv;
+    }
+    out.nodes.resize(order.size() * 2);
     for (size_t k = 0; k < order.size(); ++k) {
         const BuildNode &nd = bld.nodes[(size_t)order[k]];
-        float lo[2][3], hi[2][3];
-        for (int c = 0; c < 2; ++c)
-            for (int a = 0; a < 3; ++a) {
-                lo[c][a] = round_down(nd.box[c].lo[a]);
-                hi[c][a] = round_up(nd.box[c].hi[a]);
-            }
+        uint32_t lo[2][3] = {{0, 0, 0}, {0, 0, 0}}, hi[2][3] = {{0, 0, 0}, {0, 0, 0}};
         int32_t ref[2];
-        for (int c = 0; c < 2; ++c) ref[c] = nd.ref[c] >= 0 ? new_index[(size_t)nd.ref[c]] : nd.ref[c];
-        out.nodes[4 * k + 0] = make_float4(lo[0][0], lo[0][1], lo[0][2], hi[0][0]);
-        out.nodes[4 * k + 1] = make_float4(hi[0][1], hi[0][2], lo[1][0], lo[1][1]);
-        out.nodes[4 * k + 2] = make_float4(lo[1][2], hi[1][0], hi[1][1], hi[1][2]);
-        out.nodes[4 * k + 3] = make_float4(int_bits(ref[0]), int_bits(ref[1]), 0.0f, 0.0f);
+        for (int c = 0; c < 2; ++c) {
+            ref[c] = nd.ref[c] >= 0 ? new_index[(size_t)nd.ref[c]] : nd.ref[c];
+            if (ref[c] == kBvhEmpty) continue;
+            for (int a = 0; a < 3; ++a) {
+                lo[c][a] = grid_lo(nd.box[c].lo[a], base[a], inv_step[a]);
+                hi[c][a] = grid_hi(nd.box[c].hi[a], base[a], inv_step[a]);
+            }
+        }
+        out.nodes[2 * k + 0] = make_uint4(lo[0][0] | lo[0][1] << 16, lo[0][2] | hi[0][0] << 16,
+                                          hi[0][1] | hi[0][2] << 16, lo[1][0] | lo[1][1] << 16);
+        out.nodes[2 * k + 1] = make_uint4(lo[1][2] | hi[1][0] << 16, hi[1][1] | hi[1][2] << 16,
+                                          (uint32_t)ref[0], (uint32_t)ref[1]);
     }
     out.depth = bld.depth;
 }

@@ -7,13 +7,16 @@
 // index.  Node boxes are padded so that rounding in the exact object test can never report
 // a hit outside its node.
 //
-// Node layout (64 bytes, 4 x float4; both children's boxes live in the parent so one
-// fetch decides both):
-//   f[0] = lo0.x lo0.y lo0.z hi0.x
-//   f[1] = hi0.y hi0.z lo1.x lo1.y
-//   f[2] = lo1.z hi1.x hi1.y hi1.z
-//   f[3] = ref0 ref1 - - (int bits): ref >= 0 -> inner node index; ref < 0 -> leaf holding
-//                                    object ~ref; kBvhEmpty -> no child
+// Node layout (32 bytes, 2 x uint4; both children's boxes live in the parent so one fetch
+// decides both).  Box corners are 16-bit coordinates on a grid that spans all bounded objects:
+// world x = grid_base + q / grid_inv_step.  The traversal is bound by the number of divergent
+// memory instructions per node visit (every lane is at another node), not by arithmetic, so
+// halving the node to two 16-byte loads is worth the unpacking; the grid only has to be
+// conservative, which the builder ensures by rounding outwards with one grid unit to spare.
+//   w[0] = lo0.x | lo0.y << 16    w[1] = lo0.z | hi0.x << 16    w[2] = hi0.y | hi0.z << 16
+//   w[3] = lo1.x | lo1.y << 16    w[4] = lo1.z | hi1.x << 16    w[5] = hi1.y | hi1.z << 16
+//   w[6] = ref0   w[7] = ref1:    ref >= 0 -> inner node index; ref < 0 -> leaf holding
+//                                 object ~ref; kBvhEmpty -> no child
 // Every leaf holds exactly one object (an object test costs about five node tests, so
 // larger leaves lose).  Nodes are stored in breadth-first order, so the first K nodes are
 // the top levels.  The tree is at most kBvhMaxDepth deep: the builder switches from the
@@ -30,9 +33,12 @@ namespace rtx {
 constexpr int kBvhMaxDepth = 30;
 constexpr int kBvhStackSize = 32;
 constexpr int32_t kBvhEmpty = INT32_MIN;
+constexpr int kBvhGridMax = 65535;      // largest grid coordinate
 
 struct BvhHost {
-    std::vector<float4> nodes;       // 4 float4 per node
+    std::vector<uint4> nodes;        // 2 uint4 per node
+    float grid_base[3] = {0, 0, 0};  // world coordinate of grid coordinate 0, per axis
+    float grid_inv_step[3] = {1, 1, 1};  // grid units per world unit
     std::vector<int32_t> planes;     // unbounded (or unboundable) objects, tested by every ray
     int depth = 0;
 };

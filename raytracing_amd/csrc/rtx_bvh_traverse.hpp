@@ -29,18 +29,27 @@ RTX_DEV void bvh_try_object(const Table &tab, int pi, V3 o, V3 d, float ray_leng
     }
 }
 
-// entry distance of the ray into a box, or "miss"; conservative (boxes are padded)
-RTX_DEV bool slab_test(V3 lo, V3 hi, V3 o, V3 inv, float t_limit, float &t_near)
+// Entry distance of the ray into a node box, or "miss".  Box corners are grid coordinates
+// (16-bit integers, exact in f32); inv is the reciprocal of the ray direction in grid units
+// and oi = origin (in grid units) * inv, so q * inv - oi is the world-space distance at which
+// the ray crosses grid plane q (numerator and denominator carry the same scale).  One fused
+// multiply-add per plane.  Conservative: the builder's outward rounding leaves a grid unit to
+// spare, the f32 rounding here stays below 0.4 unit for origins within kBvhFarOrigin units.
+// For a direction component of exactly 0 the products are inf - inf = NaN, which fminf / fmaxf
+// ignore: that axis then never culls (more nodes visited by such a ray, the same result).
+RTX_DEV bool slab_test(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, V3 oi, V3 inv,
+                       float t_limit, float &t_near)
 {
-    float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
-    float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
-    float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
-    // fminf / fmaxf ignore a NaN operand (0 * inf when the origin lies on a slab plane)
+    float x0 = __builtin_fmaf((float)lx, inv.x, -oi.x), x1 = __builtin_fmaf((float)hx, inv.x, -oi.x);
+    float y0 = __builtin_fmaf((float)ly, inv.y, -oi.y), y1 = __builtin_fmaf((float)hy, inv.y, -oi.y);
+    float z0 = __builtin_fmaf((float)lz, inv.z, -oi.z), z1 = __builtin_fmaf((float)hz, inv.z, -oi.z);
     float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
     t_near = tn;
     return tn <= tf && !(tn > t_limit);
 }
+// a ray that starts farther than this many grid units from the grid takes every node
+constexpr float kBvhFarOrigin = 2.0e6f;
 
 // BLOCK = threads per workgroup of the calling kernel (the stack array is sized for it).
 //
@@ -60,17 +69,29 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
         bvh_try_object<STATS>(tab, B.planes[i], o, d, ray_length, best, best_t, cnt);
     if (B.n_nodes == 0) return best;
 
-    const V3 inv = v3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // the ray on the node grid
+    const V3 gs = v3(B.grid_inv_step[0], B.grid_inv_step[1], B.grid_inv_step[2]);
+    const V3 og = cmul(o - v3(B.grid_base[0], B.grid_base[1], B.grid_base[2]), gs);
+    const V3 dg = cmul(d, gs);
+    const V3 inv = v3(1.0f / dg.x, 1.0f / dg.y, 1.0f / dg.z);
+    const V3 oi = cmul(og, inv);
+    // written so that a NaN origin counts as far
+    const bool far = !(fmaxf(fmaxf(fabsf(og.x), fabsf(og.y)), fabsf(og.z)) < kBvhFarOrigin);
     int sp = 0;
     int32_t cur = 0;  // >= 0 inner node, < 0 leaf of object ~cur, kBvhEmpty = finished
     for (;;) {
+        // node phase: every lane descends until it holds a leaf or has finished
         while (cur >= 0) {
-            const float4 *nd = B.nodes + 4 * (size_t)cur;
-            float4 f0 = nd[0], f1 = nd[1], f2 = nd[2], f3 = nd[3];
-            const int32_t r0 = __float_as_int(f3.x), r1 = __float_as_int(f3.y);
-            float d0, d1;
-            bool h0 = r0 != kBvhEmpty && slab_test(v3(f0.x, f0.y, f0.z), v3(f0.w, f1.x, f1.y), o, inv, best_t, d0);
-            bool h1 = r1 != kBvhEmpty && slab_test(v3(f1.z, f1.w, f2.x), v3(f2.y, f2.z, f2.w), o, inv, best_t, d1);
+            const uint4 *nd = B.nodes + 2 * (size_t)cur;
+            const uint4 a = nd[0], b = nd[1];
+            const int32_t r0 = (int32_t)b.z, r1 = (int32_t)b.w;
+            float d0 = 0.0f, d1 = 0.0f;
+            bool h0 = slab_test(a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, oi,
+                                inv, best_t, d0);
+            bool h1 = slab_test(a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, oi,
+                                inv, best_t, d1);
+            h0 = (h0 || far) && r0 != kBvhEmpty;
+            h1 = (h1 || far) && r1 != kBvhEmpty;
             if constexpr (STATS) cnt.v[C_NODE_TESTS] += 2;
             if (h0 && h1) {
                 const bool first0 = d0 <= d1;
@@ -89,7 +110,8 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
             }
         }
         if (__ballot(cur != kBvhEmpty) == 0ull) break;
-        if (cur != kBvhEmpty) {
+        // leaf phase
+        if (cur < 0 && cur != kBvhEmpty) {
             bvh_try_object<STATS>(tab, ~cur, o, d, ray_length, best, best_t, cnt);
             if (sp > 0) {
                 sp--;

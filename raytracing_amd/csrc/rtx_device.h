@@ -32,7 +32,9 @@ enum : int {
 };
 
 struct BvhView {
-    const float4 *nodes;   // 4 float4 per node, see rtx_bvh.h
+    const uint4 *nodes;    // 2 uint4 per node, see rtx_bvh.h
+    float grid_base[3];    // node boxes are in grid coordinates: q = (x - grid_base) * grid_inv_step
+    float grid_inv_step[3];
     const int32_t *planes; // objects that are tested for every ray
     uint32_t n_nodes, n_planes;
 };

@@ -460,3 +460,36 @@ def test_device_tonemap_matches_the_host_output_stage():
     want = host.to_bytes(host.color_correction((x.cpu().numpy() / np.float32(2.0))))
     assert np.abs(out.cpu().numpy().astype(int) - want.astype(int)).max() <= 1
     assert out.cpu().numpy()[[0, 3, 4]].tolist() == want[[0, 3, 4]].tolist()
+
+
+def test_bvh_node_grid_extremes(oracle):
+    """Node boxes live on a 16-bit grid spanning all bounded objects.  A far-away outlier
+    coarsens the grid, a camera far outside it takes the always-descend path, axis-parallel
+    rays make the slab arithmetic produce NaNs: each must still give the scan's bits."""
+    from raytracing_amd import Prim
+    base = synthetic_scene(n_prims=200, seed=11, width=48, height=32, n_samples=2, ray_depth=4)
+    cases = {
+        "outlier": base.replace(prims=base.prims + [Prim(_abi.ELLIPSOID, (3, 2, 1), position=(4e6, -2e6, 1e7),
+                                                         color=(0.5, 0.5, 0.5))]),
+        "far camera": base.replace(cam_pos=(0.0, 0.0, 3.0e8), fov_x=4e-7),
+        "axis parallel": base.replace(width=33, height=33, cam_pos=(0.0, 0.0, 40.0), cam_forward=(0.0, 0.0, -1.0)),
+        "flat": base.replace(prims=base.prims[:6] + [Prim(_abi.BOX, (1, 1, 0.0), position=(x, y, 0.0), color=(1, 1, 1))
+                                                     for x in range(-4, 5, 2) for y in range(-4, 5, 2)]),
+    }
+    for name, sc in cases.items():
+        with Renderer(seed=5, accel=_abi.ACCEL_BRUTE_SCALAR) as r:
+            ids, t, n, ins = r.primary(sc)
+            want = r.render(sc)
+        for mode in (_abi.MODE_MEGAKERNEL, _abi.MODE_WAVEFRONT):
+            with Renderer(seed=5, accel=_abi.ACCEL_BVH, mode=mode) as r:
+                gids, gt, gn, gins = r.primary(sc)
+                got = r.render(sc)
+            assert np.array_equal(ids, gids), name
+            assert np.array_equal(t.view(np.uint32), gt.view(np.uint32)), name
+            assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), name
+        if name != "far camera":
+            assert (ids >= 6).any(), name          # the bounded objects are seen
+    oids, ot, *_ = oracle.primary(cases["far camera"])
+    with Renderer(accel=_abi.ACCEL_BVH) as r:
+        gids, gt, *_ = r.primary(cases["far camera"])
+    assert np.array_equal(oids, gids) and np.array_equal(ot.view(np.uint32), gt.view(np.uint32))
