@@ -67,3 +67,18 @@ def test_product_package_does_not_import_the_oracle():
             if fn.endswith((".py", ".hip", ".cpp", ".h", ".hpp")) or fn == "Makefile":
                 text = open(os.path.join(dirpath, fn), errors="replace").read()
                 assert "pyoracle" not in text and "rt_oracle" not in text and "import oracle" not in text, fn
+
+
+def test_rust_bindings_name_the_header_functions_and_fields():
+    """integration/rtx-sys cannot be compiled here (no Rust toolchain); at least its extern
+    block and struct fields must be the header's, in the header's order."""
+    rs = open(os.path.join(ROOT, "integration", "rtx-sys", "src", "lib.rs")).read()
+    extern = rs[rs.index('extern "C" {'):]
+    extern = extern[:extern.index("\n}\n")]
+    assert sorted(re.findall(r"pub fn (rtx_[a-z_0-9]+)\(", extern)) == header_functions()
+    assert f"RTX_ABI_VERSION: u32 = {_abi.RTX_ABI_VERSION};" in rs
+    for name, ctype in (("rtx_prim", _abi.rtx_prim), ("rtx_scene", _abi.rtx_scene), ("rtx_opts", _abi.rtx_opts),
+                        ("rtx_stats", _abi.rtx_stats)):
+        body = rs[rs.index(f"pub struct {name} {{"):]
+        body = body[:body.index("\n}\n")]
+        assert re.findall(r"pub ([a-z_0-9]+):", body) == [f for f, _ in ctype._fields_], name
