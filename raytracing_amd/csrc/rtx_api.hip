@@ -271,6 +271,14 @@ int upload_scene(rtx_ctx *c)
     P.bvh.planes = reinterpret_cast<const int32_t *>(base + off_planes);
     P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / 2);
     P.bvh.n_planes = (uint32_t)bvh.planes.size();
+    {
+        // objects outside the always-tested list are the leaves
+        std::vector<char> listed(n, 0);
+        for (int32_t i : bvh.planes) listed[(size_t)i] = 1;
+        bool all = true;
+        for (size_t i = 0; i < n; ++i) all = all && (listed[i] || is_identity_pose(c->prims[i]));
+        P.bvh.leaves_identity = all ? 1u : 0u;
+    }
     return RTX_OK;
 }
 

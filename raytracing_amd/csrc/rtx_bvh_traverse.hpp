@@ -11,17 +11,31 @@
 
 namespace rtx {
 
-template <bool STATS>
+// UNIFORM: every lane tests the same object (the list of unbounded objects), which allows the
+// shortcuts of the linear scan: no rotations for an identity pose when every lane's ray is
+// plain (all_plain), the kind read once per wave.
+template <bool STATS, bool UNIFORM = false>
 RTX_DEV void bvh_try_object(const Table &tab, int pi, V3 o, V3 d, float ray_length, int &best, float &best_t,
-                            Counters<STATS> &cnt)
+                            Counters<STATS> &cnt, bool all_plain = false)
 {
     Geom g = load_geom(tab.geom, (uint32_t)pi);
     cnt.template add<C_PTEST_PLANE>(g.kind == kPlane);
     cnt.template add<C_PTEST_ELLIPSOID>(g.kind == kEllipsoid);
     cnt.template add<C_PTEST_BOX>(g.kind == kBox);
-    LocalRay lr = to_local(g, o, d);
+    LocalRay lr;
+    int kind = g.kind;
+    if constexpr (UNIFORM) {
+        if (all_plain && (__builtin_amdgcn_readfirstlane(g.flags) & kGeomIdentity)) lr = to_local_identity(g, o, d);
+        else lr = to_local(g, o, d);
+        kind = __builtin_amdgcn_readfirstlane(g.kind | ((g.flags & kGeomPow2) << 8));
+    } else {
+        // leaves: every lane holds another object; `all_plain` is only passed as true when the
+        // whole scene's leaves have the identity pose
+        if (all_plain) lr = to_local_identity(g, o, d);
+        else lr = to_local(g, o, d);
+    }
     float t;
-    bool hit = figure_t(g.kind, g.param, lr, t);
+    bool hit = figure_t(kind, g.param, lr, t);
     hit = hit && (t * ray_length < kInf);
     if (hit && (best < 0 || t < best_t || (t == best_t && pi < best))) {
         best_t = t;
@@ -65,9 +79,11 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
     const float ray_length = len(d);
     int best = -1;
     best_t = kInf;
+    const bool all_plain = __ballot(!ray_is_plain(o, d)) == 0ull;
     for (uint32_t i = 0; i < B.n_planes; ++i)
-        bvh_try_object<STATS>(tab, B.planes[i], o, d, ray_length, best, best_t, cnt);
+        bvh_try_object<STATS, true>(tab, B.planes[i], o, d, ray_length, best, best_t, cnt, all_plain);
     if (B.n_nodes == 0) return best;
+    const bool leaves_plain = all_plain && B.leaves_identity != 0u;   // wave-uniform
 
     // the ray on the node grid
     const V3 gs = v3(B.grid_inv_step[0], B.grid_inv_step[1], B.grid_inv_step[2]);
@@ -112,7 +128,7 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
         if (__ballot(cur != kBvhEmpty) == 0ull) break;
         // leaf phase
         if (cur < 0 && cur != kBvhEmpty) {
-            bvh_try_object<STATS>(tab, ~cur, o, d, ray_length, best, best_t, cnt);
+            bvh_try_object<STATS>(tab, ~cur, o, d, ray_length, best, best_t, cnt, leaves_plain);
             if (sp > 0) {
                 sp--;
                 cur = stack[sp * BLOCK];

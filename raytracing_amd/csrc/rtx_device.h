@@ -37,6 +37,7 @@ struct BvhView {
     float grid_inv_step[3];
     const int32_t *planes; // objects that are tested for every ray
     uint32_t n_nodes, n_planes;
+    uint32_t leaves_identity;   // 1: every object in a leaf has the identity pose (kGeomIdentity)
 };
 
 // kernel parameters: passed by value, so every field sits in scalar registers
