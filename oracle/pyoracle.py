@@ -13,7 +13,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "librt_oracle.so")
+# RT_ORACLE_LIB selects another build of the oracle (the sanitizer build of `make sanitize`)
+_LIB_PATH = os.environ.get("RT_ORACLE_LIB") or os.path.join(_HERE, "librt_oracle.so")
 
 
 class orc_prim(C.Structure):
