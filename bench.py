@@ -8,7 +8,7 @@ HIP kernels, the per-GPU radiance sums combined (RCCL all-reduce when N > 1) and
 divided by the sample count.  The scene and the output buffer are resident in HBM
 before the timed region starts.
 
-Workloads (BASELINE.json configs):
+Workloads:
   c2  reference scene at 1920x1080, 256 spp, depth 6, seed 1      (default for N = 1)
   c4  reference scene at 3840x2160, 1024 spp, samples split over the N GPUs
       (default for N > 1; fixed total work, so scaling = "strong")
