@@ -23,3 +23,18 @@ np.savez_compressed(os.path.join(ROOT, "tests", "golden", "reference_scene_64x64
                     hit_id=ids, t=t, normal=n, inside=ins, radiance_seed1_4spp=img, radiance_const_xi=cx,
                     const_words=np.array(CONST_WORDS, dtype=np.uint32))
 print("written")
+
+# second file: materials, long paths, rotated objects, several lights -- in the summation order
+# the device uses (sum front to back, divide once), so a device render must equal it bit for bit
+from raytracing_amd import dielectric_scene, synthetic_scene  # noqa: E402
+
+out = {}
+for name, scene, seed in (("reference", reference_scene(width=64, height=64, n_samples=4), 1),
+                          ("dielectric", dielectric_scene(width=48, height=32, n_samples=3, ray_depth=12), 5),
+                          ("synthetic", synthetic_scene(n_prims=60, seed=9, width=48, height=32, n_samples=2, ray_depth=5,
+                                                        n_lights=3), 7)):
+    ids, t, n, ins = O.primary(scene)
+    out[name + "_hit_id"], out[name + "_t"] = ids, t
+    out[name + "_forward"] = O.render(scene, seed=seed, order=O.ORDER_FORWARD)
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", "forward_order_renders.npz"), **out)
+print("written")

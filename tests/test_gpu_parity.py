@@ -493,3 +493,29 @@ def test_bvh_node_grid_extremes(oracle):
     with Renderer(accel=_abi.ACCEL_BVH) as r:
         gids, gt, *_ = r.primary(cases["far camera"])
     assert np.array_equal(oids, gids) and np.array_equal(ot.view(np.uint32), gt.view(np.uint32))
+
+
+def test_device_equals_the_committed_golden_fixtures():
+    """The device against the fixtures directly (no oracle in the loop): hit ids, distances
+    and seeded renders of three scenes bit for bit, for every kernel variant."""
+    import os
+    from test_oracle_kat import golden_scenes
+    here = os.path.dirname(__file__)
+    g = np.load(os.path.join(here, "golden", "forward_order_renders.npz"))
+    for name, sc, seed in golden_scenes():
+        for mode in (_abi.MODE_MEGAKERNEL, _abi.MODE_WAVEFRONT):
+            for accel in (_abi.ACCEL_BRUTE_LDS, _abi.ACCEL_BRUTE_SCALAR, _abi.ACCEL_BVH):
+                with Renderer(seed=seed, mode=mode, accel=accel) as r:
+                    ids, t, _, _ = r.primary(sc)
+                    img = r.render(sc)
+                assert np.array_equal(ids, g[name + "_hit_id"]), (name, mode, accel)
+                assert np.array_equal(t.view(np.uint32), g[name + "_t"].view(np.uint32)), (name, mode, accel)
+                assert np.array_equal(img.view(np.uint32), g[name + "_forward"].view(np.uint32)), (name, mode, accel)
+    ref = np.load(os.path.join(here, "golden", "reference_scene_64x64.npz"))
+    sc = reference_scene(width=64, height=64, n_samples=4)
+    with Renderer(seed=1) as r:
+        img = r.render(sc)
+    assert rel_err(ref["radiance_seed1_4spp"], img).max() <= 1e-5      # the reference's evaluation order
+    with Renderer(rng_mode=_abi.RNG_CONST, const_words=tuple(int(x) for x in ref["const_words"])) as r:
+        cx = r.render(sc)
+    assert rel_err(ref["radiance_const_xi"], cx).max() <= 1e-5

@@ -342,3 +342,23 @@ def test_golden_fixture(oracle):
     cx = oracle.render(sc, order=oracle.ORDER_REFERENCE, rng_mode=oracle.RNG_CONST,
                        const_words=tuple(int(x) for x in g["const_words"]))
     assert np.array_equal(cx, g["radiance_const_xi"])
+
+
+def golden_scenes():
+    from raytracing_amd import dielectric_scene, synthetic_scene
+    return (("reference", reference_scene(width=64, height=64, n_samples=4), 1),
+            ("dielectric", dielectric_scene(width=48, height=32, n_samples=3, ray_depth=12), 5),
+            ("synthetic", synthetic_scene(n_prims=60, seed=9, width=48, height=32, n_samples=2, ray_depth=5, n_lights=3), 7))
+
+
+def test_golden_fixture_forward_order(oracle):
+    """Second fixture: three scenes (materials, long paths, rotated objects, several lights) in
+    the summation order the device uses."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "forward_order_renders.npz"))
+    for name, sc, seed in golden_scenes():
+        ids, t, _, _ = oracle.primary(sc)
+        assert np.array_equal(ids, g[name + "_hit_id"]), name
+        assert np.array_equal(t.view(np.uint32), g[name + "_t"].view(np.uint32)), name
+        img = oracle.render(sc, seed=seed, order=oracle.ORDER_FORWARD)
+        assert np.array_equal(img.view(np.uint32), g[name + "_forward"].view(np.uint32)), name
