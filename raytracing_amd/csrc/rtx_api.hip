@@ -170,7 +170,7 @@ int upload_scene(rtx_ctx *c)
     const size_t geom_bytes = align16(n * 3 * sizeof(float4));
     const size_t mat_bytes = align16(n * 3 * sizeof(float4));
     const size_t light_bytes = align16(nl * sizeof(int32_t));
-    const size_t lbound_bytes = align16(nl * sizeof(float4));
+    const size_t lbound_bytes = align16(nl * 2 * sizeof(float4));
 
     rtx::BvhHost bvh;
     const bool want_bvh = c->src == rtx::kSrcBvh;
@@ -208,25 +208,44 @@ int upload_scene(rtx_ctx *c)
         mat[3 * i + 2] = make_float4(p.color[0] / pi, p.color[1] / pi, p.color[2] / pi, area_pdf);
     }
     for (size_t i = 0; i < nl; ++i) lights[i] = c->lights[i];
-    // bounding sphere per light: centre = position, radius = farthest surface point, inflated
+    // Per light, what the many-lights pdf needs to skip lights a ray certainly "misses":
+    //   [2k]   bounding sphere: centre = position, squared radius (farthest surface point, +2 %)
+    //   [2k+1] x = slack: the sphere is taken larger by slack * |centre - origin|^2
+    // "Misses" means: the f32 intersection formula the pdf evaluates reports no hit -- and far
+    // from the light that formula reports hits for rays that pass well outside it.  Ellipsoid
+    // (src/objects/geometry.rs:75-91): det = b^2 - a c is off by up to 8.5e-7 |u|^2 |v|^2 (three
+    // roundings in each of a, b, c, one in each product), while its exact value is
+    // |v|^2 (1 - q^2), q = distance of the line from the centre in the scaled space where the
+    // ellipsoid is the unit sphere; so a hit can be reported while q^2 < 1 + 8.5e-7 |u|^2, and
+    // |u| <= |centre - origin| / r_min: in world units the "hit zone" is the sphere of squared
+    // radius r_max^2 + 8.5e-7 (r_max / r_min)^2 |centre - origin|^2.  Box (geometry.rs:114-130):
+    // the slab distances are off by a few 1e-7 relative, the zone grows by about
+    // 2e-6 |centre - origin|.  The slacks below are those bounds with a factor 2 to spare.
     const size_t off_lbound = geom_bytes + mat_bytes + light_bytes;
     float4 *lbound = reinterpret_cast<float4 *>(host.data() + off_lbound);
     for (size_t i = 0; i < nl; ++i) {
         const rtx_prim &p = c->prims[(size_t)c->lights[i]];
-        double q2 = 0.0, r = 0.0;
+        double q2 = 0.0, r = 0.0, rmin = INFINITY;
         for (int k = 0; k < 4; ++k) q2 += (double)p.rotation[k] * p.rotation[k];
+        for (int k = 0; k < 3; ++k) rmin = std::fmin(rmin, std::fabs((double)p.param[k]));
+        double slack;
         if (p.kind == RTX_BOX) {
             for (int k = 0; k < 3; ++k) r += (double)p.param[k] * p.param[k];
             r = std::sqrt(r);
+            slack = 1e-5;
         } else {
             for (int k = 0; k < 3; ++k) r = std::fmax(r, std::fabs((double)p.param[k]));
+            const double kappa = r / rmin;  // inf for a degenerate ellipsoid: never skipped
+            slack = 2e-6 * kappa * kappa + 2e-6;
         }
         // the rotation formula scales by |q|^2 when the quaternion is not exactly unit
         r *= std::fmax(1.0, q2) * 1.02;
         double r2 = r * r + 1e-6;
-        float r2f = (float)r2;
+        float r2f = (float)r2, slackf = (float)slack;
         if (!(r2f >= 0.0f) || !std::isfinite(r2f)) r2f = INFINITY;  // never skipped
-        lbound[i] = make_float4(p.position[0], p.position[1], p.position[2], r2f);
+        if (!(slackf >= 0.0f)) slackf = INFINITY;
+        lbound[2 * i + 0] = make_float4(p.position[0], p.position[1], p.position[2], r2f);
+        lbound[2 * i + 1] = make_float4(slackf, 0.0f, 0.0f, 0.0f);
     }
     size_t off_nodes = off_lbound + lbound_bytes;
     size_t off_planes = off_nodes + node_bytes;
@@ -268,6 +287,8 @@ int upload_scene(rtx_ctx *c)
     P.bvh.nodes = reinterpret_cast<const uint4 *>(base + off_nodes);
     std::memcpy(P.bvh.grid_base, bvh.grid_base, sizeof(P.bvh.grid_base));
     std::memcpy(P.bvh.grid_inv_step, bvh.grid_inv_step, sizeof(P.bvh.grid_inv_step));
+    std::memcpy(P.bvh.grid_step, bvh.grid_step, sizeof(P.bvh.grid_step));
+    P.bvh.far_slope = bvh.far_slope;
     P.bvh.planes = reinterpret_cast<const int32_t *>(base + off_planes);
     P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / 2);
     P.bvh.n_planes = (uint32_t)bvh.planes.size();

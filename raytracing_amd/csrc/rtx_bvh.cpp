@@ -42,8 +42,25 @@ struct Ref {
     int32_t prim;
 };
 
+// Relative error bound of det = b^2 - a c in the ellipsoid test (src/objects/geometry.rs:75-91)
+// in units of |u|^2 |v|^2: three roundings in each of a, b, c and one in each product give
+// 8.5e-7; 1e-6 is used.
+constexpr double kDetEps = 1e-6;
+// the zone in which the box test (geometry.rs:114-130) can report a hit grows by about 2e-6 of
+// the distance between the ray origin and the box; twice that is used
+constexpr double kBoxSlope = 4e-6;
+
 // World bounds of a rotated ellipsoid / box, or false when they cannot be trusted.
-bool world_bounds(const rtx_prim &p, Box3 &out)
+//
+// The bounds are not those of the geometric object but of the zone in which the reference's f32
+// test can report a hit for a ray whose origin is at most `reach` away from the object's centre
+// (every origin inside the node grid is).  For an ellipsoid the exact value of det is
+// |v|^2 (1 - q^2), q = distance of the line from the centre in the scaled space where the
+// ellipsoid is the unit sphere, and |u| <= reach / r_min, so hits are confined to
+// q^2 < 1 + kDetEps (reach / r_min)^2: the ellipsoid scaled by the square root of that.  For
+// origins farther away the zone grows by at most `slope` per unit of extra distance (the
+// traversal adds that margin per ray).
+bool world_bounds(const rtx_prim &p, double reach, Box3 &out, double &slope)
 {
     double q[4] = {p.rotation[0], p.rotation[1], p.rotation[2], p.rotation[3]};
     double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
@@ -55,10 +72,22 @@ bool world_bounds(const rtx_prim &p, Box3 &out)
                       {2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)},
                       {2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z}};
     double scale = std::max(1.0, n2);
-    double maxc = 0.0, maxe = 0.0;
+    double maxc = 0.0, maxe = 0.0, rmin = std::numeric_limits<double>::infinity(), rmax = 0.0;
     for (int k = 0; k < 3; ++k) {
         if (!std::isfinite(p.position[k]) || !std::isfinite(p.param[k])) return false;
         maxc = std::max(maxc, std::fabs((double)p.position[k]));
+        rmin = std::min(rmin, std::fabs((double)p.param[k]));
+        rmax = std::max(rmax, std::fabs((double)p.param[k]));
+    }
+    double grow = 1.0, extra = 0.0;
+    if (p.kind == RTX_ELLIPSOID) {
+        if (!(rmin > 0.0)) return false;   // a flat ellipsoid: tested by every ray
+        grow = std::sqrt(1.0 + kDetEps * (reach / rmin) * (reach / rmin));
+        slope = std::sqrt(kDetEps) * rmax / rmin;
+        if (!std::isfinite(grow) || grow > 1e3) return false;
+    } else {
+        extra = kBoxSlope * reach;
+        slope = kBoxSlope;
     }
     double e[3];
     for (int k = 0; k < 3; ++k) {
@@ -67,10 +96,10 @@ bool world_bounds(const rtx_prim &p, Box3 &out)
             double a = std::fabs(R[k][j]) * std::fabs((double)p.param[j]);
             s += (p.kind == RTX_ELLIPSOID) ? a * a : a;
         }
-        e[k] = (p.kind == RTX_ELLIPSOID ? std::sqrt(s) : s) * scale;
+        e[k] = (p.kind == RTX_ELLIPSOID ? std::sqrt(s) : s) * scale * grow + extra;
         maxe = std::max(maxe, e[k]);
     }
-    // padding: f32 rounding of the exact test is ~1e-6 of the coordinates involved
+    // padding: f32 rounding of the positions involved
     double pad = 1e-4 * (1.0 + maxc + maxe);
     for (int k = 0; k < 3; ++k) {
         out.lo[k] = (double)p.position[k] - e[k] * (1.0 + 1e-5) - pad;
@@ -214,13 +243,37 @@ void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
     out.planes.clear();
     out.depth = 0;
     Builder bld;
+    // `reach` = the largest distance between a ray origin inside the node grid and an object
+    // centre = the grid's diagonal, which itself depends on the boxes: iterate from the
+    // geometric bounds (reach 0) until it stops growing
+    double reach = 0.0;
+    for (int pass = 0; pass < 32; ++pass) {
+        Box3 all;
+        all.clear();
+        for (uint32_t i = 0; i < n; ++i) {
+            Box3 b;
+            double slope;
+            if (prims[i].kind != RTX_PLANE && world_bounds(prims[i], reach, b, slope)) all.grow(b);
+        }
+        double d2 = 0.0;
+        for (int k = 0; k < 3; ++k) d2 += all.hi[k] >= all.lo[k] ? (all.hi[k] - all.lo[k]) * (all.hi[k] - all.lo[k]) : 0.0;
+        const double diagonal = std::sqrt(d2) * 1.05;   // the grid is a little larger than the union
+        if (diagonal <= reach) break;                   // the boxes built with `reach` fit a grid within reach
+        reach = diagonal * 1.25;
+        // not converging (needle-thin ellipsoids whose zone grows faster than the scene): with an
+        // infinite reach such objects fail world_bounds and join the always-tested list
+        if (pass == 30) reach = std::numeric_limits<double>::infinity();
+    }
+    out.far_slope = (float)kBoxSlope;
     for (uint32_t i = 0; i < n; ++i) {
         Ref r;
         r.prim = (int32_t)i;
-        if (prims[i].kind == RTX_PLANE || !world_bounds(prims[i], r.box)) {
+        double slope = 0.0;
+        if (prims[i].kind == RTX_PLANE || !world_bounds(prims[i], reach, r.box, slope)) {
             out.planes.push_back((int32_t)i);
             continue;
         }
+        out.far_slope = std::max(out.far_slope, (float)(slope * 1.001));
         for (int k = 0; k < 3; ++k) r.c[k] = 0.5 * (r.box.lo[k] + r.box.hi[k]);
         bld.refs.push_back(r);
     }
@@ -264,6 +317,7 @@ void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
         float finv = 1.0f / step;
         out.grid_base[a] = fbase;
         out.grid_inv_step[a] = finv;
+        out.grid_step[a] = step;
         base[a] = (double)fbase;
         inv_step[a] = (double)finv;
     }

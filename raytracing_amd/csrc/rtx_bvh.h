@@ -39,6 +39,11 @@ struct BvhHost {
     std::vector<uint4> nodes;        // 2 uint4 per node
     float grid_base[3] = {0, 0, 0};  // world coordinate of grid coordinate 0, per axis
     float grid_inv_step[3] = {1, 1, 1};  // grid units per world unit
+    float grid_step[3] = {1, 1, 1};      // world units per grid unit
+    // Node boxes bound the zone in which the object tests can report a hit for ray origins
+    // inside the grid; for an origin x world units outside it the zone is larger by at most
+    // far_slope * x, which the traversal adds per ray.
+    float far_slope = 0.0f;
     std::vector<int32_t> planes;     // unbounded (or unboundable) objects, tested by every ray
     int depth = 0;
 };

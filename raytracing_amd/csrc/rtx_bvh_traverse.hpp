@@ -44,26 +44,28 @@ RTX_DEV void bvh_try_object(const Table &tab, int pi, V3 o, V3 d, float ray_leng
 }
 
 // Entry distance of the ray into a node box, or "miss".  Box corners are grid coordinates
-// (16-bit integers, exact in f32); inv is the reciprocal of the ray direction in grid units
-// and oi = origin (in grid units) * inv, so q * inv - oi is the world-space distance at which
-// the ray crosses grid plane q (numerator and denominator carry the same scale).  One fused
-// multiply-add per plane.  Conservative: the builder's outward rounding leaves a grid unit to
-// spare, the f32 rounding here stays below 0.4 unit for origins within kBvhFarOrigin units.
+// (16-bit integers, exact in f32); inv is the reciprocal of the ray direction in grid units,
+// oi_lo = (origin + margin) * inv and oi_hi = (origin - margin) * inv with the origin in grid
+// units, so q * inv - oi_lo is the world-space distance at which the ray crosses the low plane
+// q moved outwards by the ray's margin, and likewise for the high planes (numerator and
+// denominator carry the same scale).  One fused multiply-add per plane.  Conservative: the
+// builder rounds outwards with a grid unit to spare, and the margin (closest_hit_bvh) covers
+// the rounding of the origin and the growth of the objects' hit zones for distant origins.
 // For a direction component of exactly 0 the products are inf - inf = NaN, which fminf / fmaxf
 // ignore: that axis then never culls (more nodes visited by such a ray, the same result).
-RTX_DEV bool slab_test(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, V3 oi, V3 inv,
-                       float t_limit, float &t_near)
+RTX_DEV bool slab_test(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, V3 oi_lo, V3 oi_hi,
+                       V3 inv, float t_limit, float &t_near)
 {
-    float x0 = __builtin_fmaf((float)lx, inv.x, -oi.x), x1 = __builtin_fmaf((float)hx, inv.x, -oi.x);
-    float y0 = __builtin_fmaf((float)ly, inv.y, -oi.y), y1 = __builtin_fmaf((float)hy, inv.y, -oi.y);
-    float z0 = __builtin_fmaf((float)lz, inv.z, -oi.z), z1 = __builtin_fmaf((float)hz, inv.z, -oi.z);
+    float x0 = __builtin_fmaf((float)lx, inv.x, -oi_lo.x), x1 = __builtin_fmaf((float)hx, inv.x, -oi_hi.x);
+    float y0 = __builtin_fmaf((float)ly, inv.y, -oi_lo.y), y1 = __builtin_fmaf((float)hy, inv.y, -oi_hi.y);
+    float z0 = __builtin_fmaf((float)lz, inv.z, -oi_lo.z), z1 = __builtin_fmaf((float)hz, inv.z, -oi_hi.z);
     float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
     t_near = tn;
     return tn <= tf && !(tn > t_limit);
 }
-// a ray that starts farther than this many grid units from the grid takes every node
-constexpr float kBvhFarOrigin = 2.0e6f;
+// a ray whose margin reaches this many grid units takes every node
+constexpr float kBvhMaxMargin = 16384.0f;
 
 // BLOCK = threads per workgroup of the calling kernel (the stack array is sized for it).
 //
@@ -85,14 +87,24 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
     if (B.n_nodes == 0) return best;
     const bool leaves_plain = all_plain && B.leaves_identity != 0u;   // wave-uniform
 
-    // the ray on the node grid
+    // The ray on the node grid, and its margin.  The node boxes bound the zone in which the
+    // object tests can report a hit for origins inside the grid; the zone grows by at most
+    // far_slope per world unit the origin lies outside it (rtx_bvh.cpp: world_bounds), and the
+    // f32 value of the origin in grid units is off by up to 2^-23 of its magnitude.
     const V3 gs = v3(B.grid_inv_step[0], B.grid_inv_step[1], B.grid_inv_step[2]);
     const V3 og = cmul(o - v3(B.grid_base[0], B.grid_base[1], B.grid_base[2]), gs);
     const V3 dg = cmul(d, gs);
     const V3 inv = v3(1.0f / dg.x, 1.0f / dg.y, 1.0f / dg.z);
-    const V3 oi = cmul(og, inv);
-    // written so that a NaN origin counts as far
-    const bool far = !(fmaxf(fmaxf(fabsf(og.x), fabsf(og.y)), fabsf(og.z)) < kBvhFarOrigin);
+    const float gmax = (float)kBvhGridMax;
+    const V3 outside = v3(fmaxf(fmaxf(-og.x, og.x - gmax), 0.0f), fmaxf(fmaxf(-og.y, og.y - gmax), 0.0f),
+                          fmaxf(fmaxf(-og.z, og.z - gmax), 0.0f));                      // grid units
+    const float outside_world = (outside.x * B.grid_step[0] + outside.y * B.grid_step[1]) + outside.z * B.grid_step[2];
+    const float grow = B.far_slope * outside_world * 1.01f;                             // world units
+    const V3 margin = v3(grow * gs.x + 4e-7f * (fabsf(og.x) + gmax), grow * gs.y + 4e-7f * (fabsf(og.y) + gmax),
+                         grow * gs.z + 4e-7f * (fabsf(og.z) + gmax));                   // grid units
+    const V3 oi_lo = cmul(og + margin, inv), oi_hi = cmul(og - margin, inv);
+    // written so that a NaN counts as far
+    const bool far = !(fmaxf(fmaxf(margin.x, margin.y), margin.z) < kBvhMaxMargin);
     int sp = 0;
     int32_t cur = 0;  // >= 0 inner node, < 0 leaf of object ~cur, kBvhEmpty = finished
     for (;;) {
@@ -102,10 +114,10 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
             const uint4 a = nd[0], b = nd[1];
             const int32_t r0 = (int32_t)b.z, r1 = (int32_t)b.w;
             float d0 = 0.0f, d1 = 0.0f;
-            bool h0 = slab_test(a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, oi,
-                                inv, best_t, d0);
-            bool h1 = slab_test(a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, oi,
-                                inv, best_t, d1);
+            bool h0 = slab_test(a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, oi_lo,
+                                oi_hi, inv, best_t, d0);
+            bool h1 = slab_test(a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, oi_lo,
+                                oi_hi, inv, best_t, d1);
             h0 = (h0 || far) && r0 != kBvhEmpty;
             h1 = (h1 || far) && r1 != kBvhEmpty;
             if constexpr (STATS) cnt.v[C_NODE_TESTS] += 2;

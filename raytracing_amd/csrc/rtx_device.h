@@ -9,7 +9,8 @@
 //   mat[3*i+2]  = color / pi (IEEE division at upload),      /
 //                 w = 1 / (8 (ab + bc + ac)) for a box (its surface pdf), else 0
 //   lights[k]   = object index of light k (emissive ellipsoids and boxes, object order)
-//   light_bounds[k] = bounding sphere of light k: centre xyz, squared radius inflated by 2 %
+//   light_bounds[2k] = bounding sphere of light k: centre xyz, squared radius inflated by 2 %
+//   light_bounds[2k+1].x = slack: the sphere counts as larger by slack * |centre - ray origin|^2
 // The scan data and the shading data are separate arrays so that the scan streams 48
 // contiguous bytes per object and never touches colours.
 #pragma once
@@ -35,6 +36,8 @@ struct BvhView {
     const uint4 *nodes;    // 2 uint4 per node, see rtx_bvh.h
     float grid_base[3];    // node boxes are in grid coordinates: q = (x - grid_base) * grid_inv_step
     float grid_inv_step[3];
+    float grid_step[3];    // world units per grid unit
+    float far_slope;       // growth of the boxes per world unit the ray origin lies outside the grid
     const int32_t *planes; // objects that are tested for every ray
     uint32_t n_nodes, n_planes;
     uint32_t leaves_identity;   // 1: every object in a leaf has the identity pose (kGeomIdentity)
@@ -45,7 +48,7 @@ struct RenderParams {
     const float4 *geom;
     const float4 *mat;
     const int32_t *lights;
-    const float4 *light_bounds;  // per light: bounding-sphere centre, squared radius
+    const float4 *light_bounds;  // two float4 per light, see above
     uint32_t n_prims, n_lights;
     uint32_t width, height, ray_depth;
     uint32_t sample_first, sample_count;

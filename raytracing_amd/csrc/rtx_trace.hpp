@@ -40,7 +40,7 @@ struct Table {
     const float4 *geom;
     const float4 *mat;
     const int32_t *lights;
-    const float4 *light_bounds;  // per light: bounding-sphere centre xyz, squared radius (inflated)
+    const float4 *light_bounds;  // two per light: (bounding-sphere centre xyz, squared radius), (slack, -, -, -)
     uint32_t n_prims, n_lights;
 };
 
@@ -304,9 +304,9 @@ RTX_DEV float intersection_pdf(const Geom &g, float box_area_pdf, V3 o, V3 d, fl
 // src/random.rs:83-109.  Returns the sum over lights divided by their number.
 //
 // With many lights almost every (ray, light) pair is a miss.  A ray that passes a light's
-// bounding sphere (radius inflated by 2 %, far above any rounding of the exact test) at a
-// distance cannot hit the light, and a miss adds nothing to the sum, so such lights are
-// skipped: each lane first collects the lights whose sphere its ray touches in a bit mask
+// bounding sphere -- enlarged by the zone in which the rounding of the exact test can still
+// report a hit -- at a distance cannot "hit" the light, and a miss adds nothing to the sum, so
+// such lights are skipped: each lane first collects the lights whose sphere its ray touches in a bit mask
 // (wave-uniform loop, ~20 instructions per light), then the lanes work through their own
 // candidates, lowest index first, which keeps the order of the additions.
 // MANY_LIGHTS selects the candidate-mask form at compile time (kernels are instantiated both
@@ -347,13 +347,17 @@ RTX_DEV float light_pdf(const Table &tab, V3 p, V3 dir, Counters<STATS> &cnt)
             const uint32_t n = tab.n_lights - chunk < 64u ? tab.n_lights - chunk : 64u;
             unsigned long long candidates = 0ull;
             for (uint32_t k = 0; k < n; ++k) {
-                const float4 b = tab.light_bounds[chunk + k];
+                const float4 b = tab.light_bounds[2 * (chunk + k)];
+                const float slack = tab.light_bounds[2 * (chunk + k) + 1].x;
                 V3 oc = v3(b.x, b.y, b.z) - p;
                 float along = dot(oc, d);
                 float oc2 = dot(oc, oc);
                 float dist2 = oc2 - along * along;
+                // the zone in which the f32 intersection formula can report a hit grows with the
+                // distance of the origin (rtx_api.hip: upload_scene)
+                const float zone2 = b.w + slack * oc2;
                 // written so that a NaN never skips a light
-                bool skip = (dist2 > b.w + 2e-6f * oc2) || (along < 0.0f && oc2 > b.w);
+                bool skip = (dist2 > zone2) || (along < 0.0f && oc2 > zone2);
                 if (!skip) candidates |= 1ull << k;
                 if constexpr (STATS) {
                     // a skipped light is a light the reference tested and missed

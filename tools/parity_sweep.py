@@ -1,0 +1,119 @@
+"""Randomised parity sweep (GPU box): many small random scenes -- mixed kinds, poses (rotated,
+identity), power-of-two and ordinary sizes, 0..7 lights of both kinds, all materials, dense
+and sparse, tilted planes -- rendered by every kernel variant and compared bit for bit with
+the CPU oracle (hit ids, distances, normals, seeded radiance).  Prints one line per mismatch
+and a summary; exit status 1 if anything differed.
+    python tools/parity_sweep.py [n_scenes] [first_seed]
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from oracle import pyoracle as O
+from raytracing_amd import _abi, Prim, Scene, normalize_quaternion
+from raytracing_amd.renderer import Renderer
+
+
+def random_scene(seed):
+    rng = np.random.default_rng(seed)
+    f = lambda a: tuple(float(np.float32(v)) for v in a)
+    room = float(rng.choice([6.0, 12.0, 40.0]))
+    prims = []
+    n_planes = int(rng.integers(0, 7))
+    axes = [(0, 1, 0), (0, -1, 0), (1, 0, 0), (-1, 0, 0), (0, 0, 1), (0, 0, -1)]
+    for k in range(n_planes):
+        n = np.array(axes[k], dtype=np.float64)
+        if rng.random() < 0.3:
+            n = n * rng.uniform(0.5, 3.0) + rng.normal(scale=0.2, size=3)      # tilted, not unit
+        rot = (0, 0, 0, 1) if rng.random() < 0.7 else normalize_quaternion(*f(rng.normal(size=4) * [0.1, 0.1, 0.1, 1]))
+        prims.append(Prim(_abi.PLANE, f(n), position=f(-np.array(axes[k]) * room), rotation=rot,
+                          color=f(rng.uniform(0.2, 1, 3)),
+                          material=_abi.METALLIC if rng.random() < 0.15 else _abi.DIFFUSE))
+    n_obj = int(rng.choice([0, 1, 3, 6, 7, 12, 40, 150]))
+    n_lights = int(rng.integers(0, 8))
+    for k in range(n_obj):
+        kind = _abi.ELLIPSOID if rng.random() < 0.5 else _abi.BOX
+        mode = rng.random()
+        if mode < 0.25:
+            size = f(rng.choice([0.25, 0.5, 1.0, 2.0], size=3))                 # powers of two
+        elif mode < 0.35:
+            size = f([rng.choice([0.5, 1.0, 2.0])] * 3)
+        else:
+            size = f(rng.uniform(0.2, room / 4, size=3))
+        pos = f(rng.uniform(-room * 0.9, room * 0.9, size=3))
+        if rng.random() < 0.1 and prims:
+            pos = prims[-1].position                                            # coincident centres: ties
+        q = rng.normal(size=4)
+        rot = (0, 0, 0, 1) if rng.random() < 0.4 else normalize_quaternion(*f(q / np.linalg.norm(q)))
+        albedo = f(rng.uniform(0.0, 1.0, size=3))
+        m = rng.random()
+        if k < n_lights:
+            e = f(rng.uniform(0.5, 20.0, size=3) * (rng.random(3) < 0.8))
+            prims.append(Prim(kind, size, position=pos, rotation=rot, color=albedo, emission=e))
+        elif m < 0.6:
+            prims.append(Prim(kind, size, position=pos, rotation=rot, color=albedo))
+        elif m < 0.8:
+            prims.append(Prim(kind, size, position=pos, rotation=rot, color=albedo, material=_abi.METALLIC))
+        else:
+            prims.append(Prim(kind, size, position=pos, rotation=rot, color=albedo, material=_abi.DIELECTRIC,
+                              ior=float(np.float32(rng.uniform(1.0, 2.4)))))
+    rng.shuffle(prims)
+    w, h = int(rng.integers(1, 49)), int(rng.integers(1, 41))
+    cam = f(rng.uniform(-room * 0.5, room * 0.5, size=3))
+    fwd = rng.normal(size=3)
+    fwd /= np.linalg.norm(fwd)
+    up = np.cross(fwd, rng.normal(size=3))
+    up /= np.linalg.norm(up)
+    right = np.cross(fwd, up)
+    if rng.random() < 0.3:
+        right, up, fwd = (1, 0, 0), (0, 1, 0), (0, 0, -1)
+        cam = (0.0, 0.0, room * 0.9)
+    return Scene(width=w, height=h, ray_depth=int(rng.integers(1, 10)), n_samples=int(rng.integers(1, 4)),
+                 background=f(rng.uniform(0, 1, 3) * (rng.random() < 0.5)), cam_pos=cam, cam_right=f(right), cam_up=f(up),
+                 cam_forward=f(fwd), fov_x=float(np.float32(rng.uniform(0.3, 2.0))), prims=list(prims))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    variants = [(m, a) for m in (_abi.MODE_MEGAKERNEL, _abi.MODE_WAVEFRONT)
+                for a in (_abi.ACCEL_AUTO, _abi.ACCEL_BRUTE_SCALAR, _abi.ACCEL_BVH)]
+    bad = 0
+    for seed in range(first, first + n):
+        sc = random_scene(seed)
+        try:
+            ids, t, nrm, ins = O.primary(sc)
+            want = O.render(sc, seed=seed, order=O.ORDER_FORWARD)
+        except Exception as e:  # the oracle refuses what the reference would panic on
+            print(f"seed {seed}: oracle: {e}")
+            continue
+        for mode, accel in variants:
+            with Renderer(seed=seed, mode=mode, accel=accel) as r:
+                try:
+                    gids, gt, gn, gins = r.primary(sc)
+                    got = r.render(sc)
+                except Exception as e:
+                    print(f"seed {seed} mode {mode} accel {accel}: {e}")
+                    bad += 1
+                    continue
+            same = lambda a, b: np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            what = []
+            if not np.array_equal(ids, gids): what.append(f"ids ({int((ids != gids).sum())})")
+            if not same(t, gt): what.append("t")
+            if not same(nrm, gn): what.append("normal")
+            if not np.array_equal(ins, gins): what.append("inside")
+            if not same(want, got): what.append(f"radiance ({int((want.view(np.uint32) != got.view(np.uint32)).any(axis=2).sum())} px)")
+            if what:
+                bad += 1
+                print(f"seed {seed} mode {mode} accel {accel} ({len(sc.prims)} objects, {sc.width}x{sc.height}, "
+                      f"depth {sc.ray_depth}): " + ", ".join(what), flush=True)
+        if (seed - first) % 25 == 24:
+            print(f"... {seed - first + 1} scenes", flush=True)
+    print(f"{n} scenes x {len(variants)} variants: {bad} mismatching renders")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
