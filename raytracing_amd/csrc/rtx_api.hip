@@ -225,21 +225,22 @@ int upload_scene(rtx_ctx *c)
     float4 *lbound = reinterpret_cast<float4 *>(host.data() + off_lbound);
     for (size_t i = 0; i < nl; ++i) {
         const rtx_prim &p = c->prims[(size_t)c->lights[i]];
-        double q2 = 0.0, r = 0.0, rmin = INFINITY;
-        for (int k = 0; k < 4; ++k) q2 += (double)p.rotation[k] * p.rotation[k];
+        double r = 0.0, rmin = INFINITY;
         for (int k = 0; k < 3; ++k) rmin = std::fmin(rmin, std::fabs((double)p.param[k]));
+        // |A|, |A^-1| of the world -> local map: both 1 for a unit quaternion (rtx_bvh.h)
+        double ainv[3][3], na = INFINITY, nai = INFINITY;
+        if (!rtx::pose_matrices(p, ainv, na, nai)) na = nai = INFINITY;   // never skipped
         double slack;
         if (p.kind == RTX_BOX) {
             for (int k = 0; k < 3; ++k) r += (double)p.param[k] * p.param[k];
             r = std::sqrt(r);
-            slack = 1e-5;
+            slack = 1e-5 * (na * nai) * (na * nai);
         } else {
             for (int k = 0; k < 3; ++k) r = std::fmax(r, std::fabs((double)p.param[k]));
-            const double kappa = r / rmin;  // inf for a degenerate ellipsoid: never skipped
+            const double kappa = r / rmin * na * nai;  // inf for a degenerate ellipsoid: never skipped
             slack = 2e-6 * kappa * kappa + 2e-6;
         }
-        // the rotation formula scales by |q|^2 when the quaternion is not exactly unit
-        r *= std::fmax(1.0, q2) * 1.02;
+        r *= 1.02 * nai;
         double r2 = r * r + 1e-6;
         float r2f = (float)r2, slackf = (float)slack;
         if (!(r2f >= 0.0f) || !std::isfinite(r2f)) r2f = INFINITY;  // never skipped

@@ -62,16 +62,8 @@ constexpr double kBoxSlope = 4e-6;
 // traversal adds that margin per ray).
 bool world_bounds(const rtx_prim &p, double reach, Box3 &out, double &slope)
 {
-    double q[4] = {p.rotation[0], p.rotation[1], p.rotation[2], p.rotation[3]};
-    double n2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
-    if (!std::isfinite(n2) || n2 <= 0.0) return false;
-    // the device rotates with the quaternion as stored; a non-unit quaternion scales by
-    // up to (|w| + |u|)^2, so bound the matrix entries with that factor
-    double x = q[0], y = q[1], z = q[2], w = q[3];
-    double R[3][3] = {{w * w + x * x - y * y - z * z, 2 * (x * y - w * z), 2 * (x * z + w * y)},
-                      {2 * (x * y + w * z), w * w - x * x + y * y - z * z, 2 * (y * z - w * x)},
-                      {2 * (x * z - w * y), 2 * (y * z + w * x), w * w - x * x - y * y + z * z}};
-    double scale = std::max(1.0, n2);
+    double ainv[3][3], na, nai;
+    if (!pose_matrices(p, ainv, na, nai)) return false;
     double maxc = 0.0, maxe = 0.0, rmin = std::numeric_limits<double>::infinity(), rmax = 0.0;
     for (int k = 0; k < 3; ++k) {
         if (!std::isfinite(p.position[k]) || !std::isfinite(p.param[k])) return false;
@@ -79,24 +71,27 @@ bool world_bounds(const rtx_prim &p, double reach, Box3 &out, double &slope)
         rmin = std::min(rmin, std::fabs((double)p.param[k]));
         rmax = std::max(rmax, std::fabs((double)p.param[k]));
     }
+    // distances in local space are at most |A| times those in world space, and local growth
+    // shows in world space multiplied by at most |A^-1| (both 1 for a unit quaternion)
+    const double reach_local = reach * na;
     double grow = 1.0, extra = 0.0;
     if (p.kind == RTX_ELLIPSOID) {
         if (!(rmin > 0.0)) return false;   // a flat ellipsoid: tested by every ray
-        grow = std::sqrt(1.0 + kDetEps * (reach / rmin) * (reach / rmin));
-        slope = std::sqrt(kDetEps) * rmax / rmin;
+        grow = std::sqrt(1.0 + kDetEps * (reach_local / rmin) * (reach_local / rmin));
+        slope = std::sqrt(kDetEps) * (rmax / rmin) * na * nai;
         if (!std::isfinite(grow) || grow > 1e3) return false;
     } else {
-        extra = kBoxSlope * reach;
-        slope = kBoxSlope;
+        extra = kBoxSlope * reach_local;
+        slope = kBoxSlope * na * nai;
     }
     double e[3];
     for (int k = 0; k < 3; ++k) {
         double s = 0.0;
         for (int j = 0; j < 3; ++j) {
-            double a = std::fabs(R[k][j]) * std::fabs((double)p.param[j]);
+            double a = std::fabs(ainv[k][j]) * (std::fabs((double)p.param[j]) * grow + extra);
             s += (p.kind == RTX_ELLIPSOID) ? a * a : a;
         }
-        e[k] = (p.kind == RTX_ELLIPSOID ? std::sqrt(s) : s) * scale * grow + extra;
+        e[k] = (p.kind == RTX_ELLIPSOID ? std::sqrt(s) : s);
         maxe = std::max(maxe, e[k]);
     }
     // padding: f32 rounding of the positions involved
@@ -236,6 +231,52 @@ uint32_t grid_hi(double x, double base, double inv_step)
 }
 
 }  // namespace
+
+static double spectral_norm(const double m[3][3])
+{
+    // power iteration on m^T m; the result is scaled up a little, so it is an upper bound in practice
+    double v[3] = {0.57, 0.58, 0.59}, lambda = 0.0;
+    for (int it = 0; it < 60; ++it) {
+        double mv[3] = {0, 0, 0}, w[3] = {0, 0, 0};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) mv[i] += m[i][j] * v[j];
+        for (int j = 0; j < 3; ++j)
+            for (int i = 0; i < 3; ++i) w[j] += m[i][j] * mv[i];
+        lambda = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+        if (!(lambda > 0.0) || !std::isfinite(lambda)) return lambda;
+        for (int j = 0; j < 3; ++j) v[j] = w[j] / lambda;
+    }
+    return std::sqrt(lambda) * 1.01;
+}
+
+bool pose_matrices(const rtx_prim &p, double a_inv[3][3], double &norm_a, double &norm_a_inv)
+{
+    const double ux = -(double)p.rotation[0], uy = -(double)p.rotation[1], uz = -(double)p.rotation[2];
+    const double w = (double)p.rotation[3];
+    double a[3][3];
+    for (int j = 0; j < 3; ++j) {
+        const double v[3] = {j == 0 ? 1.0 : 0.0, j == 1 ? 1.0 : 0.0, j == 2 ? 1.0 : 0.0};
+        const double t[3] = {2 * (uy * v[2] - uz * v[1]), 2 * (uz * v[0] - ux * v[2]), 2 * (ux * v[1] - uy * v[0])};
+        a[0][j] = v[0] + w * t[0] + (uy * t[2] - uz * t[1]);
+        a[1][j] = v[1] + w * t[1] + (uz * t[0] - ux * t[2]);
+        a[2][j] = v[2] + w * t[2] + (ux * t[1] - uy * t[0]);
+    }
+    const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                       a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    if (!std::isfinite(det) || std::fabs(det) < 1e-12) return false;
+    a_inv[0][0] = (a[1][1] * a[2][2] - a[1][2] * a[2][1]) / det;
+    a_inv[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det;
+    a_inv[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det;
+    a_inv[1][0] = (a[1][2] * a[2][0] - a[1][0] * a[2][2]) / det;
+    a_inv[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det;
+    a_inv[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det;
+    a_inv[2][0] = (a[1][0] * a[2][1] - a[1][1] * a[2][0]) / det;
+    a_inv[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det;
+    a_inv[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det;
+    norm_a = spectral_norm(a);
+    norm_a_inv = spectral_norm(a_inv);
+    return std::isfinite(norm_a) && std::isfinite(norm_a_inv) && norm_a > 0.0 && norm_a_inv > 0.0;
+}
 
 void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
 {

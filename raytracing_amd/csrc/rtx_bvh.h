@@ -50,4 +50,11 @@ struct BvhHost {
 
 void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out);
 
+// The linear map the object tests apply to (world point - position) and to world directions
+// (src/objects/geometry.rs:24-27): v -> v + w t + u x t, t = 2 u x v with (u, w) the conjugate
+// of the stored quaternion.  It is a rotation only for a unit quaternion; for any other it is a
+// general matrix A, and the object in world space is A^-1 applied to the local shape.
+// Returns false if A is singular or not finite; otherwise A^-1 and the spectral norms of both.
+bool pose_matrices(const rtx_prim &p, double a_inv[3][3], double &norm_a, double &norm_a_inv);
+
 }  // namespace rtx

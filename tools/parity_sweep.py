@@ -75,14 +75,69 @@ def random_scene(seed):
                  cam_forward=f(fwd), fov_x=float(np.float32(rng.uniform(0.3, 2.0))), prims=list(prims))
 
 
+FEATURES = ("scale", "negsize", "zerosize", "zeroplane", "farpos", "quat", "negquat", "lights", "ior", "color")
+
+
+def extreme_scene(seed, features=None):
+    """Inputs a careful author would not write but the C ABI accepts: quaternions that are not
+    unit, negative / zero / tiny / huge sizes, zero plane normals, objects a hundred thousand
+    units away, up to 80 lights, refractive indices below 1, albedo above 1.  `features`
+    restricts the oddities to the named ones (FEATURES)."""
+    on = set(FEATURES if features is None else features)
+    rng = np.random.default_rng(seed + 1_000_000)
+    f = lambda a: tuple(float(np.float32(v)) for v in a)
+    base = random_scene(seed)
+    prims = list(base.prims)
+    n_extra = int(rng.integers(1, 90))
+    many_lights = "lights" in on and rng.random() < 0.3
+    for k in range(n_extra):
+        kind = int(rng.integers(0, 3))
+        size = rng.uniform(0.05, 3.0, size=3)
+        if "scale" in on:
+            size = size * rng.choice([1.0, 1.0, 1.0, 1e-3, 50.0])
+        if "negsize" in on and rng.random() < 0.15:
+            size = size * rng.choice([-1.0, 1.0], size=3)
+        if "zerosize" in on and rng.random() < 0.08:
+            size[int(rng.integers(0, 3))] = 0.0
+        if "zeroplane" in on and kind == _abi.PLANE and rng.random() < 0.1:
+            size = np.zeros(3)
+        pos = rng.uniform(-10, 10, size=3)
+        if "farpos" in on:
+            pos = pos * rng.choice([1.0, 1.0, 1.0, 100.0, 1e5])
+        q = rng.normal(size=4)
+        q = q / np.linalg.norm(q)
+        if "quat" in on:
+            q = q * rng.choice([1.0, 1.0, 0.5, 1.5, 1.0001])
+        if "negquat" in on and rng.random() < 0.05:
+            q = np.array([0.0, 0.0, 0.0, -1.0])
+        emission = (0, 0, 0)
+        if many_lights or rng.random() < 0.1:
+            emission = f(rng.uniform(0, 30, size=3))
+        if kind == _abi.BOX and any(emission) and not (size > 0).all():
+            size = np.abs(size) + 0.01                   # emissive boxes need positive sizes
+        material = int(rng.integers(0, 3))
+        ior = 1.5
+        if "ior" in on:
+            ior = float(np.float32(rng.choice([0.3, 0.9, 1.0, 1.5, 3.0])))
+        prims.append(Prim(kind, f(size), position=f(pos), rotation=f(q),
+                          color=f(rng.uniform(0, 1.2 if "color" in on else 1.0, size=3)),
+                          emission=emission, material=material, ior=ior if material == _abi.DIELECTRIC else 1.0))
+    rng.shuffle(prims)
+    return base.replace(prims=list(prims))
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     variants = [(m, a) for m in (_abi.MODE_MEGAKERNEL, _abi.MODE_WAVEFRONT)
                 for a in (_abi.ACCEL_AUTO, _abi.ACCEL_BRUTE_SCALAR, _abi.ACCEL_BVH)]
     bad = 0
+    make = random_scene
+    if os.environ.get("SWEEP_EXTREME"):     # "1" = every oddity, or a comma-separated list of FEATURES ("" entries allowed)
+        feats = None if os.environ["SWEEP_EXTREME"] == "1" else [x for x in os.environ["SWEEP_EXTREME"].split(",") if x]
+        make = lambda seed: extreme_scene(seed, feats)
     for seed in range(first, first + n):
-        sc = random_scene(seed)
+        sc = make(seed)
         try:
             ids, t, nrm, ins = O.primary(sc)
             want = O.render(sc, seed=seed, order=O.ORDER_FORWARD)
@@ -98,13 +153,14 @@ def main():
                     print(f"seed {seed} mode {mode} accel {accel}: {e}")
                     bad += 1
                     continue
-            same = lambda a, b: np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            # bit for bit, except that any NaN equals any NaN (payloads and signs carry no meaning)
+            same = lambda a, b: bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
             what = []
             if not np.array_equal(ids, gids): what.append(f"ids ({int((ids != gids).sum())})")
             if not same(t, gt): what.append("t")
             if not same(nrm, gn): what.append("normal")
             if not np.array_equal(ins, gins): what.append("inside")
-            if not same(want, got): what.append(f"radiance ({int((want.view(np.uint32) != got.view(np.uint32)).any(axis=2).sum())} px)")
+            if not same(want, got): what.append(f"radiance ({int(((want.view(np.uint32) != got.view(np.uint32)) & ~(np.isnan(want) & np.isnan(got))).any(axis=2).sum())} px)")
             if what:
                 bad += 1
                 print(f"seed {seed} mode {mode} accel {accel} ({len(sc.prims)} objects, {sc.width}x{sc.height}, "
