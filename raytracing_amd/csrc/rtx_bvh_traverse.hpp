@@ -52,7 +52,8 @@ RTX_DEV void bvh_try_object(const Table &tab, int pi, V3 o, V3 d, float ray_leng
 // builder rounds outwards with a grid unit to spare, and the margin (closest_hit_bvh) covers
 // the rounding of the origin and the growth of the objects' hit zones for distant origins.
 // For a direction component of exactly 0 the products are inf - inf = NaN, which fminf / fmaxf
-// ignore: that axis then never culls (more nodes visited by such a ray, the same result).
+// ignore: that axis then never culls (more nodes visited by such a ray, the same result); the
+// caller passes NaN offsets for an axis whose products could overflow, to the same effect.
 RTX_DEV bool slab_test(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, V3 oi_lo, V3 oi_hi,
                        V3 inv, float t_limit, float &t_near)
 {
@@ -102,7 +103,14 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
     const float grow = B.far_slope * outside_world * 1.01f;                             // world units
     const V3 margin = v3(grow * gs.x + 4e-7f * (fabsf(og.x) + gmax), grow * gs.y + 4e-7f * (fabsf(og.y) + gmax),
                          grow * gs.z + 4e-7f * (fabsf(og.z) + gmax));                   // grid units
-    const V3 oi_lo = cmul(og + margin, inv), oi_hi = cmul(og - margin, inv);
+    V3 oi_lo = cmul(og + margin, inv), oi_hi = cmul(og - margin, inv);
+    // q * inv - oi must not overflow in either product (then it would no longer be the distance
+    // to plane q): an axis on which it could -- a direction almost parallel to the planes, on a
+    // grid stretched by a far-away object -- gets NaN offsets and never culls
+    const float kNaN = __int_as_float(0x7fc00000);
+    if (!(fabsf(inv.x) * (fabsf(og.x) + margin.x + gmax) < 3e38f)) oi_lo.x = oi_hi.x = kNaN;
+    if (!(fabsf(inv.y) * (fabsf(og.y) + margin.y + gmax) < 3e38f)) oi_lo.y = oi_hi.y = kNaN;
+    if (!(fabsf(inv.z) * (fabsf(og.z) + margin.z + gmax) < 3e38f)) oi_lo.z = oi_hi.z = kNaN;
     // written so that a NaN counts as far
     const bool far = !(fmaxf(fmaxf(margin.x, margin.y), margin.z) < kBvhMaxMargin);
     int sp = 0;

@@ -534,6 +534,7 @@ def test_random_scene_sweep_and_its_past_failures(oracle):
     # inputs only the C ABI lets through: quaternions that are not unit (the world -> local map is
     # then no rotation, which the bounds have to follow), zero sizes, and the other oddities
     scenes += [(seed, extreme_scene(seed, ["quat"])) for seed in (1, 9, 36, 64, 981)]
+    scenes += [(858, extreme_scene(858, ["huge"]))]       # an object 1e31 away stretches the node grid: overflow in the slab products
     scenes += [(seed, extreme_scene(seed)) for seed in range(30)]
     variants = [(m, a) for m in (_abi.MODE_MEGAKERNEL, _abi.MODE_WAVEFRONT)
                 for a in (_abi.ACCEL_AUTO, _abi.ACCEL_BRUTE_SCALAR, _abi.ACCEL_BVH)]

@@ -10,11 +10,12 @@ import torch
 from oracle import pyoracle as O
 from raytracing_amd import _abi
 from raytracing_amd.renderer import Renderer
-from parity_sweep import random_scene
+from parity_sweep import random_scene, extreme_scene
 
 accel = {"auto": _abi.ACCEL_AUTO, "scalar": _abi.ACCEL_BRUTE_SCALAR, "bvh": _abi.ACCEL_BVH}[sys.argv[1]]
 for seed in [int(a) for a in sys.argv[2:]]:
-    sc = random_scene(seed)
+    feats = os.environ.get("SWEEP_EXTREME")
+    sc = random_scene(seed) if not feats else extreme_scene(seed, None if feats == "1" else [x for x in feats.split(",") if x])
     kinds = [p.kind for p in sc.prims]
     print(f"seed {seed}: {len(sc.prims)} objects kinds {kinds.count(0)}/{kinds.count(1)}/{kinds.count(2)}, lights {sc.light_indices()}, "
           f"{sc.width}x{sc.height}, depth {sc.ray_depth}, spp {sc.n_samples}")

@@ -75,7 +75,8 @@ def random_scene(seed):
                  cam_forward=f(fwd), fov_x=float(np.float32(rng.uniform(0.3, 2.0))), prims=list(prims))
 
 
-FEATURES = ("scale", "negsize", "zerosize", "zeroplane", "farpos", "quat", "negquat", "lights", "ior", "color")
+FEATURES = ("scale", "negsize", "zerosize", "zeroplane", "farpos", "quat", "negquat", "lights", "ior", "color",
+            "negzero", "huge")
 
 
 def extreme_scene(seed, features=None):
@@ -110,6 +111,12 @@ def extreme_scene(seed, features=None):
             q = q * rng.choice([1.0, 1.0, 0.5, 1.5, 1.0001])
         if "negquat" in on and rng.random() < 0.05:
             q = np.array([0.0, 0.0, 0.0, -1.0])
+        if "negzero" in on and rng.random() < 0.3:       # exact zeros of either sign, axis-aligned values
+            pos = np.where(rng.random(3) < 0.5, rng.choice([-0.0, 0.0], size=3), np.round(pos))
+            if kind == _abi.PLANE:
+                size = np.where(rng.random(3) < 0.6, rng.choice([-0.0, 0.0], size=3), rng.choice([-1.0, 1.0, 2.0], size=3))
+        if "huge" in on and rng.random() < 0.05:
+            pos = pos * rng.choice([1e12, 1e31, 1e-30])
         emission = (0, 0, 0)
         if many_lights or rng.random() < 0.1:
             emission = f(rng.uniform(0, 30, size=3))
@@ -123,7 +130,12 @@ def extreme_scene(seed, features=None):
                           color=f(rng.uniform(0, 1.2 if "color" in on else 1.0, size=3)),
                           emission=emission, material=material, ior=ior if material == _abi.DIELECTRIC else 1.0))
     rng.shuffle(prims)
-    return base.replace(prims=list(prims))
+    out = base.replace(prims=list(prims))
+    if "negzero" in on and rng.random() < 0.5:
+        out = out.replace(cam_pos=f(np.where(rng.random(3) < 0.5, -0.0, np.round(np.array(base.cam_pos)))),
+                          cam_right=(1.0, 0.0, -0.0), cam_up=(-0.0, 1.0, 0.0), cam_forward=(0.0, -0.0, -1.0),
+                          width=base.width | 1, height=base.height | 1)
+    return out
 
 
 def main():
@@ -136,8 +148,11 @@ def main():
     if os.environ.get("SWEEP_EXTREME"):     # "1" = every oddity, or a comma-separated list of FEATURES ("" entries allowed)
         feats = None if os.environ["SWEEP_EXTREME"] == "1" else [x for x in os.environ["SWEEP_EXTREME"].split(",") if x]
         make = lambda seed: extreme_scene(seed, feats)
+    big = int(os.environ.get("SWEEP_BIG", "1"))   # image edge and sample count multiplier
     for seed in range(first, first + n):
         sc = make(seed)
+        if big > 1:
+            sc = sc.replace(width=sc.width * big, height=sc.height * big, n_samples=sc.n_samples * big)
         try:
             ids, t, nrm, ins = O.primary(sc)
             want = O.render(sc, seed=seed, order=O.ORDER_FORWARD)
