@@ -4,6 +4,10 @@ and sparse, tilted planes -- rendered by every kernel variant and compared bit f
 the CPU oracle (hit ids, distances, normals, seeded radiance).  Prints one line per mismatch
 and a summary; exit status 1 if anything differed.
     python tools/parity_sweep.py [n_scenes] [first_seed]
+Environment: SWEEP_EXTREME=1 (or a comma-separated list of FEATURES) adds inputs only the C ABI
+lets through; SWEEP_BIG=k multiplies image edges and sample counts by k; SWEEP_OPTIONS=1 checks
+the other inputs of a render instead (64-bit seeds, sample ranges near 2^32, sums continued over
+two calls, constant draw words) and the event counters.
 """
 import os
 import sys
@@ -138,6 +142,51 @@ def extreme_scene(seed, features=None):
     return out
 
 
+def check_options(sc, seed, variants, same):
+    """The other inputs of a render: 64-bit seeds, sample ranges far from zero, sums continued
+    over several calls, constant draw words, event counters.  Returns the number of mismatches."""
+    import torch
+    rng = np.random.default_rng(seed + 7_000_000)
+    seed64 = int(rng.integers(0, 2**63)) * 2 + int(rng.integers(0, 2))
+    first = int(rng.choice([0, 1, 255, 2**31 - 2, 2**32 - 40]))
+    count = int(rng.integers(1, 5))
+    cut = int(rng.integers(0, count + 1))
+    const = rng.random() < 0.25
+    words = tuple(int(x) for x in rng.integers(0, 2**32, size=4))
+    if const and rng.random() < 0.5:
+        words = tuple(int(x) for x in rng.choice([0, 0x80000000, 0x40000000, 0xFFFFFFFF, 0xC0000000, 0x7FFFFFFF], size=4))
+    kw = dict(seed=seed64, rng_mode=O.RNG_CONST if const else O.RNG_PHILOX, const_words=words)
+    want, wstats = O.render(sc, order=O.ORDER_FORWARD, sample_first=first, sample_count=count, output_sum=True,
+                            want_stats=True, **kw)
+    bad = 0
+    buf = torch.empty(sc.width * sc.height * 3, dtype=torch.float32, device="cuda")
+    for mode, accel in variants:
+        with Renderer(seed=seed64, mode=mode, accel=accel, rng_mode=_abi.RNG_CONST if const else _abi.RNG_PHILOX,
+                      const_words=words, collect_stats=True) as r:
+            r.set_scene(sc)
+            r.render_samples(first, count, buf.data_ptr())
+            torch.cuda.synchronize()
+            whole = buf.cpu().numpy().reshape(want.shape)
+            gstats = r.stats()
+            r.render_samples(first, cut, buf.data_ptr())
+            r.accumulate_samples(first + cut, count - cut, buf.data_ptr())
+            torch.cuda.synchronize()
+            parts = buf.cpu().numpy().reshape(want.shape)
+        what = []
+        if not same(want, whole): what.append("sum")
+        if not same(want, parts): what.append(f"sum continued at {cut}")
+        nodes = gstats.pop("bvh_node_tests")
+        if nodes:
+            gstats["prim_tests"] = wstats["prim_tests"]
+        if gstats != wstats:
+            what.append("counters " + ", ".join(k for k in wstats if wstats[k] != gstats[k]))
+        if what:
+            bad += 1
+            print(f"seed {seed} mode {mode} accel {accel} ({len(sc.prims)} objects, {sc.width}x{sc.height}, depth {sc.ray_depth}, "
+                  f"samples {first}+{count}, const {const}): " + ", ".join(what), flush=True)
+    return bad
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -149,10 +198,17 @@ def main():
         feats = None if os.environ["SWEEP_EXTREME"] == "1" else [x for x in os.environ["SWEEP_EXTREME"].split(",") if x]
         make = lambda seed: extreme_scene(seed, feats)
     big = int(os.environ.get("SWEEP_BIG", "1"))   # image edge and sample count multiplier
+    options = os.environ.get("SWEEP_OPTIONS") == "1"
+    same = lambda a, b: bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
     for seed in range(first, first + n):
         sc = make(seed)
         if big > 1:
             sc = sc.replace(width=sc.width * big, height=sc.height * big, n_samples=sc.n_samples * big)
+        if options:
+            bad += check_options(sc, seed, variants, same)
+            if (seed - first) % 25 == 24:
+                print(f"... {seed - first + 1} scenes", flush=True)
+            continue
         try:
             ids, t, nrm, ins = O.primary(sc)
             want = O.render(sc, seed=seed, order=O.ORDER_FORWARD)
@@ -168,8 +224,6 @@ def main():
                     print(f"seed {seed} mode {mode} accel {accel}: {e}")
                     bad += 1
                     continue
-            # bit for bit, except that any NaN equals any NaN (payloads and signs carry no meaning)
-            same = lambda a, b: bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
             what = []
             if not np.array_equal(ids, gids): what.append(f"ids ({int((ids != gids).sum())})")
             if not same(t, gt): what.append("t")
