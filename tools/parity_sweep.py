@@ -7,7 +7,8 @@ and a summary; exit status 1 if anything differed.
 Environment: SWEEP_EXTREME=1 (or a comma-separated list of FEATURES) adds inputs only the C ABI
 lets through; SWEEP_BIG=k multiplies image edges and sample counts by k; SWEEP_OPTIONS=1 checks
 the other inputs of a render instead (64-bit seeds, sample ranges near 2^32, sums continued over
-two calls, constant draw words) and the event counters.
+two calls, constant draw words) and the event counters; SWEEP_REUSE=1 keeps one context per
+kernel variant for the whole sweep.
 """
 import os
 import sys
@@ -199,6 +200,8 @@ def main():
         make = lambda seed: extreme_scene(seed, feats)
     big = int(os.environ.get("SWEEP_BIG", "1"))   # image edge and sample count multiplier
     options = os.environ.get("SWEEP_OPTIONS") == "1"
+    reuse = os.environ.get("SWEEP_REUSE") == "1"
+    kept = {}
     same = lambda a, b: bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
     for seed in range(first, first + n):
         sc = make(seed)
@@ -211,19 +214,27 @@ def main():
             continue
         try:
             ids, t, nrm, ins = O.primary(sc)
-            want = O.render(sc, seed=seed, order=O.ORDER_FORWARD)
+            want = O.render(sc, seed=1 if reuse else seed, order=O.ORDER_FORWARD)
         except Exception as e:  # the oracle refuses what the reference would panic on
             print(f"seed {seed}: oracle: {e}")
             continue
         for mode, accel in variants:
-            with Renderer(seed=seed, mode=mode, accel=accel) as r:
-                try:
-                    gids, gt, gn, gins = r.primary(sc)
-                    got = r.render(sc)
-                except Exception as e:
-                    print(f"seed {seed} mode {mode} accel {accel}: {e}")
-                    bad += 1
-                    continue
+            if reuse:      # one context per variant for the whole sweep (seed 1): buffers and scene state are reused
+                if (mode, accel) not in kept:
+                    kept[(mode, accel)] = Renderer(seed=1, mode=mode, accel=accel)
+                r = kept[(mode, accel)]
+            else:
+                r = Renderer(seed=seed, mode=mode, accel=accel)
+            try:
+                gids, gt, gn, gins = r.primary(sc)
+                got = r.render(sc)
+            except Exception as e:
+                print(f"seed {seed} mode {mode} accel {accel}: {e}")
+                bad += 1
+                continue
+            finally:
+                if not reuse:
+                    r.close()
             what = []
             if not np.array_equal(ids, gids): what.append(f"ids ({int((ids != gids).sum())})")
             if not same(t, gt): what.append("t")
