@@ -33,7 +33,7 @@ class orc_scene(C.Structure):
 class orc_opts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("rng_mode", C.c_uint32), ("const_words", C.c_uint32 * 4),
                 ("order", C.c_uint32), ("sample_first", C.c_uint32), ("sample_count", C.c_uint32),
-                ("output_sum", C.c_uint32)]
+                ("output_sum", C.c_uint32), ("col_first", C.c_uint32), ("col_count", C.c_uint32)]
 
 
 class orc_stats(C.Structure):
@@ -121,13 +121,37 @@ def c_scene(scene):
 
 
 def render(scene, seed=1, order=ORDER_REFERENCE, rng_mode=RNG_PHILOX, const_words=(0, 0, 0, 0),
-           sample_first=0, sample_count=0, output_sum=False, want_stats=False):
+           sample_first=0, sample_count=0, output_sum=False, want_stats=False, threads=1):
+    """threads > 1: disjoint column bands rendered concurrently (the C call releases the GIL);
+    pixels are independent, so the image is the single-thread one.  No statistics then."""
     s, keep = c_scene(scene)
-    o = orc_opts()
-    o.seed, o.rng_mode, o.order = seed, rng_mode, order
-    o.const_words[:] = const_words
-    o.sample_first, o.sample_count, o.output_sum = sample_first, sample_count, int(output_sum)
     out = np.zeros((scene.height, scene.width, 3), dtype=np.float32)
+
+    def options(col_first=0, col_count=0):
+        o = orc_opts()
+        o.seed, o.rng_mode, o.order = seed, rng_mode, order
+        o.const_words[:] = const_words
+        o.sample_first, o.sample_count, o.output_sum = sample_first, sample_count, int(output_sum)
+        o.col_first, o.col_count = col_first, col_count
+        return o
+
+    if threads > 1 and scene.width > 1:
+        if want_stats:
+            raise ValueError("statistics are collected by single-thread renders only")
+        from concurrent.futures import ThreadPoolExecutor
+        bands = min(scene.width, threads * 8)
+        edges = [scene.width * k // bands for k in range(bands + 1)]
+
+        def band(k):
+            o = options(edges[k], edges[k + 1] - edges[k])
+            return lib().orc_render(C.byref(s), C.byref(o), _fp(out), None) if edges[k + 1] > edges[k] else 0
+
+        with ThreadPoolExecutor(threads) as pool:
+            rcs = list(pool.map(band, range(bands)))
+        if any(rcs):
+            raise RuntimeError(f"orc_render failed: {rcs}")
+        return out
+    o = options()
     st = orc_stats()
     rc = lib().orc_render(C.byref(s), C.byref(o), _fp(out), C.byref(st) if want_stats else None)
     if rc != 0:

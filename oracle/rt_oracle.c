@@ -607,11 +607,17 @@ int orc_render(const orc_scene *sc, const orc_opts *opts, float *rgb, orc_stats 
     if (stats) memset(stats, 0, sizeof(*stats));
     if (ctx_init(&c, sc, opts, opts->order == ORC_ORDER_FORWARD ? stats : NULL)) return -2;
     const uint32_t w = sc->width, h = sc->height;
-    memset(rgb, 0, sizeof(float) * 3u * (size_t)w * h);
+    uint32_t i0 = 0, i1 = w;
+    if (opts->col_count) {
+        i0 = opts->col_first < w ? opts->col_first : w;
+        i1 = opts->col_count < w - i0 ? i0 + opts->col_count : w;
+    } else {
+        memset(rgb, 0, sizeof(float) * 3u * (size_t)w * h);
+    }
 
     if (opts->order == ORC_ORDER_REFERENCE) {
         for (uint32_t step = 0; step < sc->n_samples; ++step) {
-            for (uint32_t i = 0; i < w; ++i) {
+            for (uint32_t i = i0; i < i1; ++i) {
                 for (uint32_t j = 0; j < h; ++j) {
                     uint32_t pixel = (h - 1 - j) * w + i;
                     uint32_t blk[4];
@@ -631,7 +637,7 @@ int orc_render(const orc_scene *sc, const orc_opts *opts, float *rgb, orc_stats 
     } else {
         uint32_t first = opts->sample_first;
         uint32_t count = opts->sample_count ? opts->sample_count : sc->n_samples;
-        for (uint32_t i = 0; i < w; ++i) {
+        for (uint32_t i = i0; i < i1; ++i) {
             for (uint32_t j = 0; j < h; ++j) {
                 uint32_t pixel = (h - 1 - j) * w + i;
                 v3 sum = V(0, 0, 0);

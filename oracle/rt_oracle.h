@@ -72,6 +72,10 @@ typedef struct {
     uint32_t sample_first;   /* FORWARD only: first global sample index */
     uint32_t sample_count;   /* FORWARD only: 0 = all n_samples */
     uint32_t output_sum;     /* FORWARD only: 1 = leave the per-pixel sum undivided */
+    uint32_t col_first;      /* render only image columns [col_first, col_first + col_count) and leave */
+    uint32_t col_count;      /* the rest of rgb untouched; 0 = the whole image (rgb is zeroed first).
+                              * Pixels are independent, so disjoint bands may be rendered into one
+                              * buffer concurrently by several threads (a test convenience). */
 } orc_opts;
 
 /* event counters of one render (FORWARD order), for FLOP accounting */

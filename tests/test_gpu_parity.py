@@ -549,3 +549,18 @@ def test_random_scene_sweep_and_its_past_failures(oracle):
             assert np.array_equal(ids, gids), (seed, mode, accel)
             assert same(t, gt) and same(n, gn), (seed, mode, accel)          # any NaN equals any NaN
             assert same(want, got), (seed, mode, accel)
+
+
+def test_full_resolution_render_equals_the_oracle(oracle):
+    """The benchmark's resolution, 1920x1080 (32 400 waves, every tile shape of the launch),
+    at 16 of its 256 samples per pixel: all 2 073 600 pixels bit for bit.  The oracle renders
+    column bands on the host's threads.  (tools/full_size_parity.py does the same at the full
+    256 spp, 531 M samples, in about a minute.)"""
+    import os
+    sc = reference_scene(width=1920, height=1080, n_samples=16)
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    want = oracle.render(sc, seed=1, order=oracle.ORDER_FORWARD, threads=threads)
+    with Renderer(seed=1) as r:
+        got = r.render(sc)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    assert 0.05 < float(got.mean()) < 0.2

@@ -362,3 +362,13 @@ def test_golden_fixture_forward_order(oracle):
         assert np.array_equal(t.view(np.uint32), g[name + "_t"].view(np.uint32)), name
         img = oracle.render(sc, seed=seed, order=oracle.ORDER_FORWARD)
         assert np.array_equal(img.view(np.uint32), g[name + "_forward"].view(np.uint32)), name
+
+
+def test_column_bands_on_threads_give_the_same_image(oracle):
+    sc = reference_scene(width=37, height=11, n_samples=3)
+    for order in (oracle.ORDER_FORWARD, oracle.ORDER_REFERENCE):
+        one = oracle.render(sc, seed=4, order=order)
+        many = oracle.render(sc, seed=4, order=order, threads=5)
+        assert np.array_equal(one.view(np.uint32), many.view(np.uint32))
+    with pytest.raises(ValueError):
+        oracle.render(sc, threads=2, want_stats=True)
