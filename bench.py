@@ -64,10 +64,17 @@ def cpu_baseline(scene, seconds_target=15.0):
     pyoracle.render(sample, seed=1, order=pyoracle.ORDER_REFERENCE)
     dt = time.perf_counter() - t0
     n = sample.width * sample.height * sample.n_samples
+    # for orientation only: the same sample with the image's columns spread over this job's
+    # host threads (the reference itself is single-threaded, src/main.rs:13-31)
+    threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "16")), len(os.sched_getaffinity(0))))
+    t0 = time.perf_counter()
+    pyoracle.render(sample, seed=1, order=pyoracle.ORDER_REFERENCE, threads=threads)
+    dt_all = time.perf_counter() - t0
     return {"value": n / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
             "sample": f"same scene at 480x270, {spp} spp ({n} samples, {dt:.1f} s), "
                       "C restatement of the reference (not the Rust binary), gcc -O2 -ffp-contract=off, 1 thread",
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(),
+            "all_threads": {"value": n / dt_all / 1e6, "unit": "Msamples/s", "cores": threads}}
 
 
 def measured_traffic(workload, mode, n_gpus):
