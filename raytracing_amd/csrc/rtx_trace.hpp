@@ -403,9 +403,6 @@ RTX_DEV float mis_pdf(const Table &tab, V3 p, V3 n, V3 d, Counters<STATS> &cnt)
 {
     float a = tab.n_lights == 0 ? 1.0f : 0.5f;
     float cos_pdf = rmax(dot(n, d), 0.0f) / kPi;
-#if defined(RTX_ABLATE) && RTX_ABLATE == 1
-    return cos_pdf * a + (p.x * 1e-9f + 0.05f) * (1.0f - a);
-#endif
     return cos_pdf * a + light_pdf<STATS, MANY_LIGHTS>(tab, p, d, cnt) * (1.0f - a);
 }
 
@@ -498,13 +495,6 @@ struct Path {
 RTX_DEV uint4 draw_block(const RenderParams &P, uint32_t pixel, uint32_t sample, uint32_t slot)
 {
     if (P.rng_const) return make_uint4(P.const_words[0], P.const_words[1], P.const_words[2], P.const_words[3]);
-#if defined(RTX_ABLATE) && RTX_ABLATE == 4
-    {
-        uint32_t h = (pixel * 0x9E3779B9u) ^ (sample * 0x85EBCA6Bu) ^ (slot * 0xC2B2AE35u) ^ P.seed_lo;
-        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
-        return make_uint4(h, h * 0x297A2D39u, h * 0x85EBCA6Bu + 0x1234567u, h * 0xC2B2AE35u + 0x7654321u);
-    }
-#endif
     return philox4x32_10(pixel, sample, slot, 0u, P.seed_lo, P.seed_hi);
 }
 
@@ -543,13 +533,7 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
     float4 m0 = tab.mat[3 * idx + 0], m1 = tab.mat[3 * idx + 1];
     V3 color = v3(m0.x, m0.y, m0.z);
 
-#if defined(RTX_ABLATE) && RTX_ABLATE == 3
-    Hit h;
-    h.n = -p.d;
-    h.inside = false;
-#else
     Hit h = finish_hit(tab, idx, p.o, p.d, t, material == kDielectric);
-#endif
     V3 point = p.o + p.d * t;
     V3 n = h.n;
 
@@ -559,19 +543,10 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
         uint4 w = draw_block(P, pixel, sample, p.depth + 1);
         V3 new_dir;
         bool pick_cosine = tab.n_lights == 0 || (w.x >> 31) == 0u;
-#if defined(RTX_ABLATE) && RTX_ABLATE == 2
-        new_dir = n + v3(u24(w.y) - 0.5f, u24(w.z) - 0.5f, u24(w.w) - 0.5f);
-        if (false) {
-#else
         if (pick_cosine) {
-#endif
             cnt.template add<C_COSINE>();
             new_dir = cosine_sample(n, w.y, w.z);
-#if defined(RTX_ABLATE) && RTX_ABLATE == 2
-        } else if (false) {
-#else
         } else {
-#endif
             uint32_t li = __umulhi(w.x << 2, tab.n_lights);
             Geom lg = load_geom(tab.geom, (uint32_t)tab.lights[li]);
             cnt.template add<C_LSAMPLE_ELLIPSOID>(lg.kind == kEllipsoid);
