@@ -4,8 +4,9 @@
 // thousands of objects the scan is replaced by a binary BVH over the ellipsoids and boxes;
 // planes are unbounded and stay in a list that every ray tests.  The traversal returns
 // exactly what the scan returns: the smallest distance, ties going to the lowest object
-// index.  Node boxes are padded so that rounding in the exact object test can never report
-// a hit outside its node.
+// index.  A leaf box bounds not the geometric object but the zone in which the reference's f32
+// object test can report a hit (rtx_bvh.cpp: world_bounds): far from an ellipsoid that test
+// "hits" rays passing well outside it, and the scan would return those hits.
 //
 // Node layout (32 bytes, 2 x uint4; both children's boxes live in the parent so one fetch
 // decides both).  Box corners are 16-bit coordinates on a grid that spans all bounded objects:
