@@ -33,7 +33,8 @@ class orc_scene(C.Structure):
 class orc_opts(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("rng_mode", C.c_uint32), ("const_words", C.c_uint32 * 4),
                 ("order", C.c_uint32), ("sample_first", C.c_uint32), ("sample_count", C.c_uint32),
-                ("output_sum", C.c_uint32), ("col_first", C.c_uint32), ("col_count", C.c_uint32)]
+                ("output_sum", C.c_uint32), ("full_paths", C.c_uint32), ("col_first", C.c_uint32),
+                ("col_count", C.c_uint32)]
 
 
 class orc_stats(C.Structure):
@@ -71,6 +72,8 @@ def lib():
         fp = C.POINTER(C.c_float)
         L.orc_render.restype = C.c_int
         L.orc_render.argtypes = [C.POINTER(orc_scene), C.POINTER(orc_opts), fp, C.POINTER(orc_stats)]
+        L.orc_scene_is_tame.restype = C.c_int
+        L.orc_scene_is_tame.argtypes = [C.POINTER(orc_scene)]
         L.orc_primary.restype = C.c_int
         L.orc_primary.argtypes = [C.POINTER(orc_scene), C.POINTER(C.c_int32), fp, fp, C.POINTER(C.c_uint8)]
         L.orc_closest_hit.restype = C.c_int
@@ -121,7 +124,7 @@ def c_scene(scene):
 
 
 def render(scene, seed=1, order=ORDER_REFERENCE, rng_mode=RNG_PHILOX, const_words=(0, 0, 0, 0),
-           sample_first=0, sample_count=0, output_sum=False, want_stats=False, threads=1):
+           sample_first=0, sample_count=0, output_sum=False, want_stats=False, threads=1, full_paths=False):
     """threads > 1: disjoint column bands rendered concurrently (the C call releases the GIL);
     pixels are independent, so the image is the single-thread one.  No statistics then."""
     s, keep = c_scene(scene)
@@ -132,6 +135,7 @@ def render(scene, seed=1, order=ORDER_REFERENCE, rng_mode=RNG_PHILOX, const_word
         o.seed, o.rng_mode, o.order = seed, rng_mode, order
         o.const_words[:] = const_words
         o.sample_first, o.sample_count, o.output_sum = sample_first, sample_count, int(output_sum)
+        o.full_paths = int(full_paths)
         o.col_first, o.col_count = col_first, col_count
         return o
 
@@ -157,6 +161,11 @@ def render(scene, seed=1, order=ORDER_REFERENCE, rng_mode=RNG_PHILOX, const_word
     if rc != 0:
         raise RuntimeError(f"orc_render failed: {rc}")
     return (out, st.as_dict()) if want_stats else out
+
+
+def scene_is_tame(scene):
+    s, keep = c_scene(scene)
+    return bool(lib().orc_scene_is_tame(C.byref(s)))
 
 
 def primary(scene):

@@ -137,6 +137,7 @@ typedef struct {
     int n_lights;
     int32_t *lights;
     orc_stats *stats; /* may be NULL */
+    int stop_on_zero; /* FORWARD order: end a path whose throughput is exactly zero */
 } ctx_t;
 
 static void draw_block(const ctx_t *c, uint32_t pixel, uint32_t sample, uint32_t slot, uint32_t w[4])
@@ -561,6 +562,8 @@ static v3 trace_forward(ctx_t *c, ray_t r, uint32_t pixel, uint32_t sample)
             }
             if (st) st->dielectric_bounces++;
         }
+        /* every later term is T * (finite emission or background) = +-0: nothing can change L */
+        if (c->stop_on_zero && T.x == 0.0f && T.y == 0.0f && T.z == 0.0f) break;
     }
     return L;
 }
@@ -587,9 +590,47 @@ static int collect_lights(const orc_scene *sc, int32_t *out, int cap)
     }
     return n;
 }
+static int tame(float x, float lo, float hi)
+{
+    float a = fabsf(x);
+    return a >= lo && a <= hi; /* false for NaN */
+}
+
+int orc_scene_is_tame(const orc_scene *sc)
+{
+    if (!sc) return 0;
+    for (int k = 0; k < 3; ++k)
+        if (!tame(sc->background[k], 0.0f, 1e6f)) return 0;
+    for (uint32_t i = 0; i < sc->n_prims; ++i) {
+        const orc_prim *p = &sc->prims[i];
+        float q2 = 0.0f;
+        int nonzero = 0;
+        for (int k = 0; k < 3; ++k) {
+            if (!tame(p->emission[k], 0.0f, 1e6f) || !tame(p->color[k], 0.0f, 1e3f)) return 0;
+            if (!tame(p->position[k], 0.0f, 1e6f)) return 0;
+            if (p->kind == ORC_PLANE) {
+                if (!tame(p->param[k], 0.0f, 1e6f)) return 0;
+                nonzero |= fabsf(p->param[k]) >= 1e-6f;
+            } else {
+                if (!tame(p->param[k], 1e-4f, 1e6f)) return 0;
+                nonzero = 1;
+            }
+        }
+        if (!nonzero) return 0;
+        for (int k = 0; k < 4; ++k) {
+            if (!tame(p->rotation[k], 0.0f, 2.0f)) return 0;
+            q2 += p->rotation[k] * p->rotation[k];
+        }
+        if (!(q2 >= 0.5f && q2 <= 2.0f)) return 0;
+        if (p->material == ORC_DIELECTRIC && !tame(p->ior, 1e-3f, 1e3f)) return 0;
+    }
+    return 1;
+}
+
 static int ctx_init(ctx_t *c, const orc_scene *sc, const orc_opts *opts, orc_stats *stats)
 {
     c->scene = sc; c->opts = opts; c->stats = stats;
+    c->stop_on_zero = opts->order == ORC_ORDER_FORWARD && !opts->full_paths && orc_scene_is_tame(sc);
     c->n_lights = collect_lights(sc, NULL, 0);
     c->lights = (int32_t *)malloc(sizeof(int32_t) * (size_t)(c->n_lights > 0 ? c->n_lights : 1));
     if (!c->lights) return -1;

@@ -72,6 +72,8 @@ typedef struct {
     uint32_t sample_first;   /* FORWARD only: first global sample index */
     uint32_t sample_count;   /* FORWARD only: 0 = all n_samples */
     uint32_t output_sum;     /* FORWARD only: 1 = leave the per-pixel sum undivided */
+    uint32_t full_paths;     /* FORWARD only: 1 = never end a path early on a zero throughput (see
+                              * orc_scene_is_tame); the image is the same bit for bit either way */
     uint32_t col_first;      /* render only image columns [col_first, col_first + col_count) and leave */
     uint32_t col_count;      /* the rest of rgb untouched; 0 = the whole image (rgb is zeroed first).
                               * Pixels are independent, so disjoint bands may be rendered into one
@@ -96,6 +98,14 @@ typedef struct {
 
 /* full render: rgb = width*height*3 floats, row 0 = TOP row (image.rs:21-29) */
 int orc_render(const orc_scene *scene, const orc_opts *opts, float *rgb, orc_stats *stats_or_null);
+
+/* 1 if every number of the scene is finite, no object is degenerate (zero plane normal, zero
+ * radius or half-size) and magnitudes are moderate.  In such a scene a path whose throughput
+ * has become exactly (0, 0, 0) -- it bounced off a black object, like the light of
+ * assets/scene.txt:38-41, which has no COLOR -- can only add T * emission = +-0 from then on,
+ * and x + (+-0) = x: the FORWARD order ends the path there (the reference goes on tracing it,
+ * trace.rs:43-48, to no effect).  The device applies the same rule with the same predicate. */
+int orc_scene_is_tame(const orc_scene *scene);
 
 /* deterministic primary visibility through pixel centres (du = dv = 0.5):
  * hit_id = -1 on a miss; t, normal (w*h*3) and inside undefined there (written 0). */

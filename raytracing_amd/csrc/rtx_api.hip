@@ -137,6 +137,43 @@ bool is_pow2_param(const rtx_prim &p)
     return true;
 }
 
+// Every number finite and moderate, no degenerate object: the condition under which a path
+// with zero throughput may be ended (rtx_trace.hpp: bounce).  Magnitude limits keep every
+// intermediate of the trace loop finite, so the zero cannot meet an inf or a NaN later on.
+bool tame(float x, float lo, float hi)
+{
+    const float a = std::fabs(x);
+    return a >= lo && a <= hi;  // false for NaN
+}
+bool scene_is_tame(const rtx_scene &s, const std::vector<rtx_prim> &prims)
+{
+    for (int k = 0; k < 3; ++k)
+        if (!tame(s.background[k], 0.0f, 1e6f)) return false;
+    for (const rtx_prim &p : prims) {
+        float q2 = 0.0f;
+        bool nonzero = false;
+        for (int k = 0; k < 3; ++k) {
+            if (!tame(p.emission[k], 0.0f, 1e6f) || !tame(p.color[k], 0.0f, 1e3f)) return false;
+            if (!tame(p.position[k], 0.0f, 1e6f)) return false;
+            if (p.kind == RTX_PLANE) {
+                if (!tame(p.param[k], 0.0f, 1e6f)) return false;
+                nonzero = nonzero || std::fabs(p.param[k]) >= 1e-6f;
+            } else {
+                if (!tame(p.param[k], 1e-4f, 1e6f)) return false;
+                nonzero = true;
+            }
+        }
+        if (!nonzero) return false;
+        for (int k = 0; k < 4; ++k) {
+            if (!tame(p.rotation[k], 0.0f, 2.0f)) return false;
+            q2 += p.rotation[k] * p.rotation[k];
+        }
+        if (!(q2 >= 0.5f && q2 <= 2.0f)) return false;
+        if (p.material == RTX_DIELECTRIC && !tame(p.ior, 1e-3f, 1e3f)) return false;
+    }
+    return true;
+}
+
 int validate_scene(const rtx_scene *s)
 {
     if (!s) return fail(RTX_ERR_INVALID_ARG, "scene is null");
@@ -284,6 +321,7 @@ int upload_scene(rtx_ctx *c)
     P.seed_lo = (uint32_t)c->opts.seed;
     P.seed_hi = (uint32_t)(c->opts.seed >> 32);
     P.rng_const = c->opts.rng_mode == RTX_RNG_CONST ? 1u : 0u;
+    P.stop_on_zero = scene_is_tame(c->scene, c->prims) ? 1u : 0u;
     std::memcpy(P.const_words, c->opts.const_words, sizeof(P.const_words));
     P.bvh.nodes = reinterpret_cast<const uint4 *>(base + off_nodes);
     std::memcpy(P.bvh.grid_base, bvh.grid_base, sizeof(P.bvh.grid_base));

@@ -61,6 +61,7 @@ struct RenderParams {
     uint32_t const_words[4];
     float *out_sum;         // width*height*3, row 0 = top
     uint32_t accumulate;    // 1: the sums continue from the values already in out_sum
+    uint32_t stop_on_zero;  // 1: a path whose throughput is exactly (0, 0, 0) ends (tame scenes only)
     unsigned long long *stats; // C_COUNT counters or nullptr
     BvhView bvh;
 };

@@ -592,6 +592,13 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
         p.d = nd;
         cnt.template add<C_DIELECTRIC>();
     }
+    // A throughput of exactly zero -- the path bounced off a black object, like the light of
+    // the reference's scene, which has no COLOR -- stays zero, and every later term of the
+    // radiance is T * (finite emission or background) = +-0, which changes nothing when added.
+    // The reference goes on tracing such a path (src/trace.rs:43-48); ending it here gives the
+    // same bits.  Only in scenes whose numbers are all finite and moderate (stop_on_zero, set
+    // at upload): a non-finite factor later on would turn the zero into a NaN.
+    if (P.stop_on_zero && p.T.x == 0.0f && p.T.y == 0.0f && p.T.z == 0.0f) return true;
     p.depth += 1;
     return false;
 }
