@@ -564,3 +564,28 @@ def test_full_resolution_render_equals_the_oracle(oracle):
         got = r.render(sc)
     assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
     assert 0.05 < float(got.mean()) < 0.2
+
+
+def test_zero_throughput_rule_matches_full_paths_and_is_off_for_untame_scenes(oracle):
+    """The device ends paths with zero throughput in tame scenes (same image, fewer rays) and
+    keeps full paths otherwise; the oracle's forward order does the same, so counters agree."""
+    from raytracing_amd import Prim
+    sc = reference_scene(width=64, height=48, n_samples=4)
+    full, full_stats = oracle.render(sc, seed=3, order=oracle.ORDER_FORWARD, want_stats=True, full_paths=True)
+    with Renderer(seed=3, collect_stats=True, accel=_abi.ACCEL_BRUTE_LDS) as r:
+        got = r.render(sc)
+        st = r.stats()
+    assert np.array_equal(full.view(np.uint32), got.view(np.uint32))
+    assert st["rays"] < 0.8 * full_stats["rays"] and st["samples"] == full_stats["samples"]
+    # an object whose colour is inf makes 0 * inf = NaN possible: full paths, NaNs where the oracle has them
+    wild = sc.replace(prims=sc.prims + [Prim(_abi.ELLIPSOID, (1, 1, 1), position=(0, 0, 2), color=(np.inf, 1, 1))])
+    assert not oracle.scene_is_tame(wild)
+    want, wstats = oracle.render(wild, seed=3, order=oracle.ORDER_FORWARD, want_stats=True)
+    with Renderer(seed=3, collect_stats=True, accel=_abi.ACCEL_BRUTE_LDS) as r:
+        got = r.render(wild)
+        st = r.stats()
+    assert np.array_equal(np.isnan(want), np.isnan(got)) and np.isnan(want).any()
+    ok = ~np.isnan(want)
+    assert np.array_equal(want[ok].view(np.uint32), got[ok].view(np.uint32))
+    st.pop("bvh_node_tests")
+    assert st == wstats
