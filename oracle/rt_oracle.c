@@ -523,6 +523,11 @@ static v3 trace_forward(ctx_t *c, ray_t r, uint32_t pixel, uint32_t sample)
         if (st) st->hits[obj->kind]++;
         L = add3(L, mul3(T, ld3(obj->emission)));
         if (depth + 1 >= sc->ray_depth) break;
+        /* A black diffuse or metallic surface: the scatter either rejects its sample or leaves
+         * T * 0 = +-0 (T, cos and pdf being finite), so the path is over either way. */
+        if (c->stop_on_zero && obj->material != ORC_DIELECTRIC && obj->color[0] == 0.0f && obj->color[1] == 0.0f &&
+            obj->color[2] == 0.0f && is_finite_f(T.x) && is_finite_f(T.y) && is_finite_f(T.z))
+            break;
         v3 point = add3(r.o, scale3(r.d, h.t));
         v3 normal = h.n;
         uint32_t w[4];

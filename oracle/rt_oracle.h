@@ -104,7 +104,9 @@ int orc_render(const orc_scene *scene, const orc_opts *opts, float *rgb, orc_sta
  * has become exactly (0, 0, 0) -- it bounced off a black object, like the light of
  * assets/scene.txt:38-41, which has no COLOR -- can only add T * emission = +-0 from then on,
  * and x + (+-0) = x: the FORWARD order ends the path there (the reference goes on tracing it,
- * trace.rs:43-48, to no effect).  The device applies the same rule with the same predicate. */
+ * trace.rs:43-48, to no effect) -- and already at the black surface itself when it is diffuse
+ * or metallic, before the scatter whose only possible outcomes are a rejected sample and a zero
+ * throughput.  The device applies the same rule with the same predicate. */
 int orc_scene_is_tame(const orc_scene *scene);
 
 /* deterministic primary visibility through pixel centres (du = dv = 0.5):

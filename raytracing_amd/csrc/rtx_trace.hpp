@@ -603,12 +603,25 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
     return false;
 }
 
+// A black diffuse or metallic surface ends the path (scenes with stop_on_zero only): the
+// scatter there either rejects its sample or leaves T * 0 = +-0 -- T, the cosine and the pdf
+// being finite -- and a path with zero throughput is over (see bounce).  Checked after the
+// surface's emission has been added, before any of the scatter's work.
+RTX_DEV bool black_surface_ends(const RenderParams &P, const Table &tab, const Path &p, int idx)
+{
+    if (!P.stop_on_zero) return false;
+    const float4 m0 = tab.mat[3 * idx + 0];
+    return __float_as_int(m0.w) != kDielectric && m0.x == 0.0f && m0.y == 0.0f && m0.z == 0.0f && finite_f(p.T.x) &&
+           finite_f(p.T.y) && finite_f(p.T.z);
+}
+
 // One whole surface interaction (emission, depth cut, material switch); true = path ended.
 template <bool STATS, bool MANY_LIGHTS>
 RTX_DEV bool scatter(const RenderParams &P, const Table &tab, Path &p, int idx, float t,
                      uint32_t pixel, uint32_t sample, Counters<STATS> &cnt)
 {
     if (surface_emission(P, tab, p, idx)) return true;
+    if (black_surface_ends(P, tab, p, idx)) return true;
     int material = __float_as_int(tab.mat[3 * idx + 0].w);
     return bounce<STATS, MANY_LIGHTS>(P, tab, p, idx, t, material, pixel, sample, cnt);
 }

@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(kWfThreads) k_wavefront(const RenderParams P, 
                             cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
                             cnt.template add<C_HIT_BOX>(kind == kBox);
                         }
-                        done = surface_emission(P, tab, p, idx);
+                        done = surface_emission(P, tab, p, idx) || black_surface_ends(P, tab, p, idx);
                     }
                     if (done) {
                         refresh = wf_finish_path(P, S, slot, pixel, p.L, w.sample);
