@@ -506,16 +506,19 @@ static int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count
     if (stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, rtx::C_COUNT * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(c->ev_start, stream));
     if (c->opts.mode == RTX_MODE_WAVEFRONT) {
-        const size_t need = rtx::wavefront_state_bytes(P.width, P.height);
-        if (c->d_wavefront_bytes < need) {
-            if (c->d_wavefront) (void)hipFree(c->d_wavefront);
-            c->d_wavefront = nullptr;
-            c->d_wavefront_bytes = 0;
-            HIP_TRY(hipMalloc(&c->d_wavefront, need));
-            c->d_wavefront_bytes = need;
-        }
         rtx::WfState S;
-        rtx::wavefront_bind_state(c->d_wavefront, P.width, P.height, S);
+        S.rec = nullptr;
+        if (!rtx::wavefront_state_in_lds(P, c->src)) {
+            const size_t need = rtx::wavefront_state_bytes(P.width, P.height);
+            if (c->d_wavefront_bytes < need) {
+                if (c->d_wavefront) (void)hipFree(c->d_wavefront);
+                c->d_wavefront = nullptr;
+                c->d_wavefront_bytes = 0;
+                HIP_TRY(hipMalloc(&c->d_wavefront, need));
+                c->d_wavefront_bytes = need;
+            }
+            rtx::wavefront_bind_state(c->d_wavefront, P.width, P.height, S);
+        }
         HIP_TRY(rtx::launch_wavefront(P, S, c->src, stats, stream));
     } else {
         HIP_TRY(rtx::launch_megakernel(P, c->src, stats, stream));

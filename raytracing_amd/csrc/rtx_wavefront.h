@@ -4,8 +4,9 @@
 
 namespace rtx {
 
-// Path state in device memory: one 64-byte record per slot (slot = workgroup * 4096 +
-// workgroup-local pixel number), so a path's whole state is one cache line:
+// Path state: one 64-byte record per pixel a workgroup owns, in LDS when the workgroup's
+// queues, records and object table fit there (wavefront_state_in_lds), else in device memory
+// at slot = workgroup * 4096 + workgroup-local pixel number, a whole cache line per path:
 //   rec[4*slot+0] = ray origin xyz      | distance of the current segment's closest hit
 //   rec[4*slot+1] = ray direction xyz   | object index of that hit (int bits)
 //   rec[4*slot+2] = throughput xyz      | depth (int bits)
@@ -14,6 +15,8 @@ struct WfState {
     float4 *rec;
 };
 
+// true: the launch keeps the records in LDS and needs no state block
+bool wavefront_state_in_lds(const RenderParams &P, int src);
 size_t wavefront_state_bytes(uint32_t width, uint32_t height);
 void wavefront_bind_state(void *block, uint32_t width, uint32_t height, WfState &S);
 // Renders samples [P.sample_first, +P.sample_count) into P.out_sum: one asynchronous launch.
