@@ -259,3 +259,17 @@ def test_host_sources_are_clean_under_sanitizers():
     out = subprocess.run([os.path.join(ROOT, "tools", "host_sanitize.sh")], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.startswith("clean:")
+
+
+@pytest.mark.gpu
+def test_python_driver_writes_the_same_file_as_the_cli(tmp_path):
+    """python -m raytracing_amd.render (the multi-GPU capable driver, here with one process)
+    against rtx_cli: same scene file, same options, same bytes."""
+    from raytracing_amd import render
+    scene_path = tmp_path / "scene.txt"
+    scene_path.write_text(SAMPLE)
+    a, b = str(tmp_path / "a.ppm"), str(tmp_path / "b.ppm")
+    opts = ["--size", "72", "40", "--spp", "5", "--seed", "9"]
+    subprocess.check_call([os.path.join(ROOT, "raytracing_amd", "rtx_cli"), str(scene_path), a] + opts)
+    assert render.main([str(scene_path), b] + opts) == 0
+    assert open(a, "rb").read() == open(b, "rb").read()
