@@ -1,6 +1,8 @@
 """Bit-for-bit comparison of the device with the CPU oracle at the benchmark's full sizes
 (GPU box; the oracle runs on all host threads, about a minute for C2):
-    python tools/full_size_parity.py [c2] [c5] [c3]
+    python tools/full_size_parity.py [--full-paths] [c2] [c5] [c3]
+--full-paths: the oracle follows every path to the depth limit, as the reference does (the
+device ends paths whose throughput is zero; the image must be the same).
 c2: reference scene 1920x1080, 256 spp.  c5: glass / metal scene, depth 16, 1920x1080, 64 spp.
 c3: 10 000 objects, 960x540, 4 spp (the oracle scans every object for every ray)."""
 import os
@@ -18,13 +20,15 @@ threads = int(os.environ.get("OMP_NUM_THREADS", "16"))
 work = {"c2": lambda: reference_scene(1920, 1080, 256, 6), "c5": lambda: dielectric_scene(1920, 1080, 64, 16),
         "c3": lambda: synthetic_scene(10000, 12345, 960, 540, 4, 6)}
 ok = True
-for name in sys.argv[1:] or ["c2"]:
+full_paths = "--full-paths" in sys.argv
+names = [a for a in sys.argv[1:] if not a.startswith("--")]
+for name in names or ["c2"]:
     sc = work[name]()
     t0 = time.time()
     with Renderer(seed=1) as r:
         got = r.render(sc)
     t1 = time.time()
-    want = O.render(sc, seed=1, order=O.ORDER_FORWARD, threads=threads)
+    want = O.render(sc, seed=1, order=O.ORDER_FORWARD, threads=threads, full_paths=full_paths)
     t2 = time.time()
     diff = (want.view(np.uint32) != got.view(np.uint32)).any(axis=2)
     ok = ok and not diff.any()
