@@ -198,7 +198,8 @@ def main():
         roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                     "frac_of_nonpacked_fma_peak": achieved / PEAK_FP32_NONPACKED_TFLOPS,
-                    "kernel": "k_megakernel" if mode == _abi.MODE_MEGAKERNEL else "wavefront stages",
+                    "kernel": ("k_megakernel (probe launch of 8 samples, k_tile_order, main launch in cost order)"
+                               if mode == _abi.MODE_MEGAKERNEL else "k_wavefront"),
                     "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_rank,
                     "flops_per_sample": flops_rank / max(1, stats["samples"]),
                     "rays_per_sample": stats["rays"] / max(1, stats["samples"])}

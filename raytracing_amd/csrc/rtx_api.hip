@@ -79,6 +79,8 @@ struct rtx_ctx {
     uint32_t progress_done = 0;
     void *d_wavefront = nullptr;  // path state of the wavefront variant
     size_t d_wavefront_bytes = 0;
+    uint32_t *d_tiles = nullptr;  // cost and dispatch order of the 8x8 tiles, n_tiles words each
+    size_t d_tiles_words = 0;
     unsigned long long *d_stats = nullptr;
     rtx_stats stats{};
     bool stats_valid = false;
@@ -443,6 +445,7 @@ void rtx_destroy(rtx_ctx *c)
     if (c->d_image) (void)hipFree(c->d_image);
     if (c->d_bytes) (void)hipFree(c->d_bytes);
     if (c->d_wavefront) (void)hipFree(c->d_wavefront);
+    if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
@@ -485,6 +488,13 @@ int rtx_set_scene(rtx_ctx *c, const rtx_scene *s)
     return RTX_OK;
 }
 
+// cost-ordered dispatch of the megakernel's tiles: used from this many samples and tiles on
+// (fewer tiles than two per wave slot of the GPU leave nothing to reorder)
+#ifndef RTX_PROBE
+#define RTX_PROBE 8u
+#endif
+constexpr uint32_t kProbeSamples = RTX_PROBE, kOrderedMinSamples = 64u, kOrderedMinTiles = 8192u;
+
 static int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream,
                         bool accumulate)
 {
@@ -521,6 +531,36 @@ static int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count
         }
         HIP_TRY(rtx::launch_wavefront(P, S, c->src, stats, stream));
     } else {
+        // Waves run one tile each and the launch ends when the last of them does; with tiles
+        // handed out in image order the last ones started can be the long ones.  A first launch
+        // of kProbeSamples samples records what each tile costs, the rest of the samples are
+        // continued on top of its sums with the tiles dispatched longest first.  The split
+        // changes no bits (the sums continue in sample order, as rtx_accumulate_samples does).
+        const uint32_t n_tiles = ((P.width + 7u) / 8u) * ((P.height + 7u) / 8u);
+        uint32_t probe = 0;
+        if (!stats && sample_count >= kOrderedMinSamples && n_tiles >= kOrderedMinTiles) {
+            probe = kProbeSamples;
+            if (c->d_tiles_words < 2u * (size_t)n_tiles) {
+                if (c->d_tiles) (void)hipFree(c->d_tiles);
+                c->d_tiles = nullptr;
+                c->d_tiles_words = 0;
+                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_tiles), 2u * (size_t)n_tiles * sizeof(uint32_t)));
+                c->d_tiles_words = 2u * (size_t)n_tiles;
+            }
+        }
+        if (probe) {
+            uint32_t *cost = c->d_tiles, *order = c->d_tiles + n_tiles;
+            HIP_TRY(hipMemsetAsync(cost, 0, n_tiles * sizeof(uint32_t), stream));
+            rtx::RenderParams A = P;
+            A.sample_count = probe;
+            A.tile_cost = cost;
+            HIP_TRY(rtx::launch_megakernel(A, c->src, false, stream));
+            HIP_TRY(rtx::launch_tile_order(cost, order, n_tiles, stream));
+            P.sample_first = sample_first + probe;
+            P.sample_count = sample_count - probe;
+            P.accumulate = 1u;
+            P.tile_order = order;
+        }
         HIP_TRY(rtx::launch_megakernel(P, c->src, stats, stream));
     }
     HIP_TRY(hipEventRecord(c->ev_stop, stream));

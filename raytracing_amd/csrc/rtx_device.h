@@ -63,6 +63,10 @@ struct RenderParams {
     uint32_t accumulate;    // 1: the sums continue from the values already in out_sum
     uint32_t stop_on_zero;  // 1: a path whose throughput is exactly (0, 0, 0) ends (tame scenes only)
     unsigned long long *stats; // C_COUNT counters or nullptr
+    // Dispatch order of the 8x8 tiles (see launch_tile_order): wave number -> tile, or nullptr for
+    // the identity; and where a recording launch leaves each tile's cost (nullptr: not recorded).
+    const uint32_t *tile_order;
+    uint32_t *tile_cost;
     BvhView bvh;
 };
 
@@ -78,6 +82,10 @@ enum : int { kSrcLds = 0, kSrcScalar = 1, kSrcBvh = 2 };
 // scenes with more than kFewLights lights run the kernels built with the candidate-mask light pdf
 constexpr uint32_t kFewLights = 2;
 hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, hipStream_t stream);
+// order[0..n_tiles) = the tiles by decreasing cost[] (buckets of one unit, costs above
+// kTileCostMax share the first bucket)
+constexpr uint32_t kTileCostMax = 2047u;
+hipError_t launch_tile_order(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_primary(const RenderParams &p, const PrimaryParams &out, int src, hipStream_t stream);
 hipError_t launch_divide(float *d, uint64_t n, float divisor, hipStream_t stream);
 hipError_t launch_tonemap(const float *sum, uint64_t n, float divisor, uint8_t *bytes, hipStream_t stream);

@@ -54,14 +54,23 @@ RTX_DEV Table global_table(const RenderParams &P)
 }
 
 // wave -> 8x8 tile, lane -> pixel inside it; rows counted from the top of the image
-RTX_DEV bool lane_pixel(const RenderParams &P, uint32_t &px, uint32_t &py)
+RTX_DEV bool lane_pixel(const RenderParams &P, uint32_t &px, uint32_t &py, uint32_t &tile)
 {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const uint32_t tiles_x = (P.width + 7u) >> 3;
+    tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (P.tile_order) {
+        if (tile >= tiles_x * ((P.height + 7u) >> 3)) return false;
+        tile = P.tile_order[tile];
+    }
     px = (tile % tiles_x) * 8u + (lane & 7u);
     py = (tile / tiles_x) * 8u + (lane >> 3);
     return px < P.width && py < P.height;
+}
+RTX_DEV bool lane_pixel(const RenderParams &P, uint32_t &px, uint32_t &py)
+{
+    uint32_t tile;
+    return lane_pixel(P, px, py, tile);
 }
 
 template <int SRC, bool STATS>
@@ -74,12 +83,15 @@ RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, flo
 #ifndef RTX_MEGAKERNEL_ATTR
 #define RTX_MEGAKERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))  // at most 128 VGPRs: 4 waves per SIMD measured fastest for the scan and the BVH kernels alike
 #endif
-template <int SRC, bool STATS, bool MANY_LIGHTS>
+// RECORD: the launch also leaves in P.tile_cost[tile] (zero before the launch) the largest number
+// of rays one pixel of the tile traced -- what the wave's running time follows.
+template <int SRC, bool STATS, bool MANY_LIGHTS, bool RECORD = false>
 __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const RenderParams P)
 {
     Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
-    uint32_t px, py;
-    if (!lane_pixel(P, px, py)) return;
+    uint32_t px, py, tile;
+    if (!lane_pixel(P, px, py, tile)) return;
+    uint32_t rays = 0;
     const uint32_t pixel = py * P.width + px;
     const uint32_t pi = px, pj = P.height - 1u - py;
 
@@ -104,6 +116,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
             cnt.template add<C_SAMPLES>();
         }
         cnt.template add<C_RAYS>();
+        if constexpr (RECORD) rays += 1u;
         float t;
         int idx = closest_hit<SRC, STATS>(P, tab, p.o, p.d, t, cnt);
         bool done;
@@ -128,6 +141,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
     out[0] = sum.x;
     out[1] = sum.y;
     out[2] = sum.z;
+    if constexpr (RECORD) atomicMax(&P.tile_cost[tile], rays);
     if constexpr (STATS) {
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i)
@@ -187,6 +201,29 @@ __global__ void __launch_bounds__(256) k_tonemap(const float *sum, uint64_t n, f
     }
 }
 
+// Counting sort of the tiles by decreasing cost, one workgroup.  Tiles of equal cost land in
+// the order their atomics happen to be served: the order table only decides which wave starts
+// when, never what it computes.
+__global__ void __launch_bounds__(1024) k_tile_order(const uint32_t *cost, uint32_t *order, uint32_t n_tiles)
+{
+    __shared__ uint32_t start[kTileCostMax + 1u];
+    for (uint32_t b = threadIdx.x; b <= kTileCostMax; b += blockDim.x) start[b] = 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_tiles; i += blockDim.x) atomicAdd(&start[min(cost[i], kTileCostMax)], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t at = 0;
+        for (uint32_t b = kTileCostMax + 1u; b-- > 0u;) {
+            const uint32_t n = start[b];
+            start[b] = at;
+            at += n;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n_tiles; i += blockDim.x)
+        order[atomicAdd(&start[min(cost[i], kTileCostMax)], 1u)] = i;
+}
+
 static dim3 tile_grid(const RenderParams &p)
 {
     uint32_t tiles = ((p.width + 7u) / 8u) * ((p.height + 7u) / 8u);
@@ -201,6 +238,9 @@ static void launch_megakernel_src(const RenderParams &p, bool stats, dim3 grid, 
     if (stats) {
         if (many) hipLaunchKernelGGL((k_megakernel<SRC, true, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((k_megakernel<SRC, true, false>), grid, block, lds, stream, p);
+    } else if (p.tile_cost) {
+        if (many) hipLaunchKernelGGL((k_megakernel<SRC, false, true, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((k_megakernel<SRC, false, false, true>), grid, block, lds, stream, p);
     } else {
         if (many) hipLaunchKernelGGL((k_megakernel<SRC, false, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((k_megakernel<SRC, false, false>), grid, block, lds, stream, p);
@@ -214,6 +254,12 @@ hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, hipStre
     if (src == kSrcLds) launch_megakernel_src<kSrcLds>(p, stats, grid, lds, stream);
     else if (src == kSrcScalar) launch_megakernel_src<kSrcScalar>(p, stats, grid, lds, stream);
     else launch_megakernel_src<kSrcBvh>(p, stats, grid, lds, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_order(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, stream, cost, order, n_tiles);
     return hipGetLastError();
 }
 

@@ -436,6 +436,33 @@ def test_progressive_steps_equal_the_one_shot_render(mode):
             r.progress_begin(sc, sum=None, samples_done=3)
 
 
+@pytest.mark.parametrize("accel", [_abi.ACCEL_BRUTE_LDS, _abi.ACCEL_BVH])
+def test_cost_ordered_dispatch_changes_no_bits(accel):
+    """From 64 samples and 8192 tiles on the megakernel renders 8 samples first, sorts the tiles
+    by what they cost and runs the rest longest tile first.  Two steps of 32 samples stay below
+    the threshold and run in image order, a counting context always does: the same bits."""
+    sc = reference_scene(width=1021, height=771, n_samples=64)      # 128 x 97 tiles, ragged edges
+    with Renderer(seed=21, accel=accel) as r:
+        ordered = r.render(sc)
+        r.progress_begin(sc)
+        r.progress_step(32)
+        r.progress_step(32)
+        plain, done = r.progress_read("mean")
+        assert done == 64
+        r.progress_begin(sc)                 # and continued on top of an existing sum
+        r.progress_step(24)
+        r.progress_step(64)
+        state, done = r.progress_read("sum")
+        assert done == 88
+    assert np.array_equal(ordered.view(np.uint32), plain.view(np.uint32))
+    with Renderer(seed=21, accel=accel, collect_stats=True) as r:
+        counted = r.render(sc)
+        assert r.stats()["samples"] == 1021 * 771 * 64
+        want = r.render(sc.replace(n_samples=88))
+    assert np.array_equal(ordered.view(np.uint32), counted.view(np.uint32))
+    assert np.array_equal((state / np.float32(88)).view(np.uint32), want.view(np.uint32))
+
+
 def test_device_tonemap_matches_the_host_output_stage():
     from raytracing_amd import host
     sc = reference_scene(width=160, height=120, n_samples=6)

@@ -12,13 +12,19 @@ src = f"gpurun_out/prof_{workload}_{mode}"
 dst = f"profiles/{rnd}"
 os.makedirs(dst, exist_ok=True)
 key = "wavefront" if mode == "wavefront" else "megakernel"
+# A counter pass runs one bench step.  A step of the megakernel can be two launches (a probe of
+# a few samples that records tile costs, then the rest in cost order): counters are summed
+# over the step's launches, so every figure is per step.
 out = {}
+kernels = []
 for d in "abcd":
     for f in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
         for r in csv.DictReader(open(f)):
             if key in r["Kernel_Name"]:
-                out[r["Counter_Name"]] = float(r["Counter_Value"])
-                out["kernel"] = r["Kernel_Name"]
+                out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+                if r["Kernel_Name"] not in kernels:
+                    kernels.append(r["Kernel_Name"])
+out["kernels"] = kernels
 if "SQ_THREAD_CYCLES_VALU" in out:
     out["thread_active_fraction"] = out["SQ_THREAD_CYCLES_VALU"] / (64 * out["SQ_ACTIVE_INST_VALU"])
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
