@@ -13,7 +13,9 @@
  * keeps no caller pointer.  No function aborts or throws: each returns
  * RTX_OK (0) or a negative rtx_status, and rtx_last_error() gives a message for
  * the calling thread's last failure.  One rtx_ctx belongs to one host thread at
- * a time and drives one GPU.
+ * a time and drives one GPU.  Renders of one context share device scratch (path
+ * state, tile order): give them one stream, or wait for one to end before the
+ * next starts on another stream.
  */
 #ifndef RTX_H
 #define RTX_H
