@@ -95,7 +95,7 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
     const V3 gs = v3(B.grid_inv_step[0], B.grid_inv_step[1], B.grid_inv_step[2]);
     const V3 og = cmul(o - v3(B.grid_base[0], B.grid_base[1], B.grid_base[2]), gs);
     const V3 dg = cmul(d, gs);
-    const V3 inv = v3(1.0f / dg.x, 1.0f / dg.y, 1.0f / dg.z);
+    const V3 inv = cdiv(v3(1.0f, 1.0f, 1.0f), dg);
     const float gmax = (float)kBvhGridMax;
     const V3 outside = v3(fmaxf(fmaxf(-og.x, og.x - gmax), 0.0f), fmaxf(fmaxf(-og.y, og.y - gmax), 0.0f),
                           fmaxf(fmaxf(-og.z, og.z - gmax), 0.0f));                      // grid units

@@ -23,14 +23,49 @@ struct V3 {
     float x, y, z;
 };
 
+typedef float F2 __attribute__((ext_vector_type(2)));
+
+// q1 = a1 / b1 and q2 = a2 / b2, both correctly rounded: the instruction sequence the compiler
+// emits for one binary32 division (scale both operands, reciprocal, two Newton steps on it, three
+// on the quotient, v_div_fmas, v_div_fixup), written out so that the six multiply / FMA steps of
+// the two quotients run as packed instructions (v_pk_fma_f32: 5.5 cycles for both against 4.1 each).
+RTX_DEV void div2(float a1, float b1, float a2, float b2, float &q1, float &q2)
+{
+    bool scaled1, scaled2, ignore;
+    const F2 d = {__builtin_amdgcn_div_scalef(a1, b1, false, &ignore), __builtin_amdgcn_div_scalef(a2, b2, false, &ignore)};
+    const F2 n = {__builtin_amdgcn_div_scalef(a1, b1, true, &scaled1), __builtin_amdgcn_div_scalef(a2, b2, true, &scaled2)};
+    const F2 r0 = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const F2 one = {1.0f, 1.0f};
+    const F2 e0 = __builtin_elementwise_fma(-d, r0, one);
+    const F2 r = __builtin_elementwise_fma(e0, r0, r0);
+    const F2 m = n * r;
+    const F2 e1 = __builtin_elementwise_fma(-d, m, n);
+    const F2 q = __builtin_elementwise_fma(e1, r, m);
+    const F2 e2 = __builtin_elementwise_fma(-d, q, n);
+    q1 = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e2.x, r.x, q.x, scaled1), b1, a1);
+    q2 = __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(e2.y, r.y, q.y, scaled2), b2, a2);
+}
+
 RTX_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
 RTX_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 RTX_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 RTX_DEV V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
 RTX_DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
-RTX_DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+RTX_DEV V3 operator/(V3 a, float s)
+{
+    V3 q;
+    div2(a.x, s, a.y, s, q.x, q.y);
+    q.z = a.z / s;
+    return q;
+}
 RTX_DEV V3 cmul(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
-RTX_DEV V3 cdiv(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
+RTX_DEV V3 cdiv(V3 a, V3 b)
+{
+    V3 q;
+    div2(a.x, b.x, a.y, b.y, q.x, q.y);
+    q.z = a.z / b.z;
+    return q;
+}
 RTX_DEV float dot(V3 a, V3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
 RTX_DEV float len2(V3 a) { return dot(a, a); }
 RTX_DEV float len(V3 a) { return __builtin_sqrtf(dot(a, a)); }

@@ -133,8 +133,8 @@ RTX_DEV bool ellipsoid_t(V3 rad, const LocalRay &r, float &t, bool pow2)
     float det = b * b - a * c;
     if (det < 0.0f) return false;
     float sq = __builtin_sqrtf(det);
-    float t1 = (-b + sq) / a;
-    float t2 = (-b - sq) / a;
+    float t1, t2;
+    div2(-b + sq, a, -b - sq, a, t1, t2);
     float lo = rmin(t1, t2), hi = rmax(t1, t2);
     if (lo > 0.0f) { t = lo; return true; }
     if (hi > 0.0f) { t = hi; return true; }
@@ -142,9 +142,10 @@ RTX_DEV bool ellipsoid_t(V3 rad, const LocalRay &r, float &t, bool pow2)
 }
 RTX_DEV bool box_t(V3 s, const LocalRay &r, float &t)
 {
-    float ax1 = (s.x - r.o.x) / r.d.x, ax2 = (-s.x - r.o.x) / r.d.x;
-    float ay1 = (s.y - r.o.y) / r.d.y, ay2 = (-s.y - r.o.y) / r.d.y;
-    float az1 = (s.z - r.o.z) / r.d.z, az2 = (-s.z - r.o.z) / r.d.z;
+    float ax1, ax2, ay1, ay2, az1, az2;
+    div2(s.x - r.o.x, r.d.x, -s.x - r.o.x, r.d.x, ax1, ax2);
+    div2(s.y - r.o.y, r.d.y, -s.y - r.o.y, r.d.y, ay1, ay2);
+    div2(s.z - r.o.z, r.d.z, -s.z - r.o.z, r.d.z, az1, az2);
     float t1 = rmax(rmax(rmin(ax1, ax2), rmin(ay1, ay2)), rmin(az1, az2));
     float t2 = rmin(rmin(rmax(ax1, ax2), rmax(ay1, ay2)), rmax(az1, az2));
     if (t1 > t2) return false;
