@@ -7,6 +7,8 @@ REFERENCE-order oracle (recursion + f32 running mean, as src/main.rs:13-31 and
 src/trace.rs:11-71 evaluate them) is matched within 1e-5 relative (the tolerance the
 task states for deterministic passes).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -434,6 +436,17 @@ def test_progressive_steps_equal_the_one_shot_render(mode):
         assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
         with pytest.raises(RtxError):
             r.progress_begin(sc, sum=None, samples_done=3)
+
+
+def test_packed_division_has_the_bits_of_the_builtin_one():
+    """rtx_math.hpp computes two quotients at a time with packed FMA steps; the checker compares
+    3.2e9 random operand pairs and all pairs of a table of special values with `/` on the GPU."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracing_amd", "check_div2")
+    assert os.path.exists(exe), "raytracing_amd/check_div2 is not built (make -C raytracing_amd/csrc)"
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=100)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert res.stdout.startswith("0 quotients differ"), res.stdout
 
 
 @pytest.mark.parametrize("accel", [_abi.ACCEL_BRUTE_LDS, _abi.ACCEL_BVH])

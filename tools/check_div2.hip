@@ -1,7 +1,7 @@
 // check_div2 -- the packed two-quotient division of rtx_math.hpp against the compiler's own
 // binary32 division, bit for bit, over random bit patterns, random ordinary numbers and every
-// pair of a table of special values.  Build and run on the GPU:
-//   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I raytracing_amd/csrc tools/check_div2.hip -o build_variants/check_div2
+// pair of a table of special values.  Built by raytracing_amd/csrc/Makefile as
+// raytracing_amd/check_div2; exit status 0 when every quotient has the bits of a / b.
 #include "rtx_math.hpp"
 #include <cstdio>
 #include <vector>
