@@ -490,10 +490,7 @@ int rtx_set_scene(rtx_ctx *c, const rtx_scene *s)
 
 // cost-ordered dispatch of the megakernel's tiles: used from this many samples and tiles on
 // (fewer tiles than two per wave slot of the GPU leave nothing to reorder)
-#ifndef RTX_PROBE
-#define RTX_PROBE 8u
-#endif
-constexpr uint32_t kProbeSamples = RTX_PROBE, kOrderedMinSamples = 64u, kOrderedMinTiles = 8192u;
+constexpr uint32_t kProbeSamples = 8u, kOrderedMinSamples = 64u, kOrderedMinTiles = 8192u;
 
 static int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream,
                         bool accumulate)
