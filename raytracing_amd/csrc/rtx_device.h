@@ -67,6 +67,7 @@ struct RenderParams {
     // the identity; and where a recording launch leaves each tile's cost (nullptr: not recorded).
     const uint32_t *tile_order;
     uint32_t *tile_cost;
+    uint32_t pool_entries;  // megakernel: float4 entries of a wave's hand-over pool in LDS (set by the launcher)
     BvhView bvh;
 };
 
@@ -85,6 +86,7 @@ hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, hipStre
 // order[0..n_tiles) = the tiles by decreasing cost[] (buckets of one unit, costs above
 // kTileCostMax share the first bucket)
 constexpr uint32_t kTileCostMax = 2047u;
+constexpr uint32_t kPoolEntriesMax = 1023u;
 hipError_t launch_tile_order(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_primary(const RenderParams &p, const PrimaryParams &out, int src, hipStream_t stream);
 hipError_t launch_divide(float *d, uint64_t n, float divisor, hipStream_t stream);

@@ -13,15 +13,18 @@
 #include "rtx_trace.hpp"
 #include "rtx_bvh_traverse.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace rtx {
 
 extern __shared__ float4 rtx_smem[];
 
-size_t scene_lds_bytes(uint32_t n_prims, uint32_t n_lights)
+__host__ __device__ inline uint32_t table_lds_bytes(uint32_t n_prims, uint32_t n_lights)
 {
-    size_t b = (size_t)n_prims * 6u * sizeof(float4) + (size_t)n_lights * sizeof(int32_t);
-    return (b + 15u) & ~(size_t)15u;
+    return (n_prims * 6u * (uint32_t)sizeof(float4) + n_lights * (uint32_t)sizeof(int32_t) + 15u) & ~15u;
 }
+size_t scene_lds_bytes(uint32_t n_prims, uint32_t n_lights) { return table_lds_bytes(n_prims, n_lights); }
 
 // copies the object table into LDS; every thread of the workgroup must call it
 RTX_DEV Table stage_table_lds(const RenderParams &P)
@@ -83,64 +86,143 @@ RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, flo
 #ifndef RTX_MEGAKERNEL_ATTR
 #define RTX_MEGAKERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))  // at most 128 VGPRs: 4 waves per SIMD measured fastest for the scan and the BVH kernels alike
 #endif
+// largest value of `v` over the wave's 64 lanes (every lane must be active)
+RTX_DEV uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, m, 64));
+    return v;
+}
+
+// A wave owns the 64 pixels of a tile and every lane the samples of one of them, added to the
+// pixel's sum in index order.  Lanes do not finish together (path lengths are random: over 256
+// samples the slowest of 64 lanes traces ~8 % more rays than the mean), so a lane that has run
+// out of samples takes over the *last* unstarted sample of the lane that has the most of them
+// left, and leaves its radiance in an entry of the wave's pool in LDS (P.pool_entries float4 per
+// wave: x, y, z, and in w the link to the entry taken from the same owner before it).  The
+// owner walks its list after its own samples -- the entry taken last holds the lowest sample
+// index -- so the pixel's sum sees the same additions in the same order as without the hand-over.
 // RECORD: the launch also leaves in P.tile_cost[tile] (zero before the launch) the largest number
-// of rays one pixel of the tile traced -- what the wave's running time follows.
+// of rays one lane of the tile's wave traced -- what the wave's running time follows.
+constexpr uint32_t kNoEntry = 0x3ffu;   // end of a list; pool entries are numbered below it
 template <int SRC, bool STATS, bool MANY_LIGHTS, bool RECORD = false>
 __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const RenderParams P)
 {
     Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
-    uint32_t px, py, tile;
-    if (!lane_pixel(P, px, py, tile)) return;
-    uint32_t rays = 0;
-    const uint32_t pixel = py * P.width + px;
-    const uint32_t pi = px, pj = P.height - 1u - py;
+    const uint32_t tiles_x = (P.width + 7u) >> 3;
+    uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (tile >= tiles_x * ((P.height + 7u) >> 3)) return;   // the whole wave
+    if (P.tile_order) tile = P.tile_order[tile];
+    const uint32_t tile_x = (tile % tiles_x) * 8u, tile_y = (tile / tiles_x) * 8u;
+    const bool in_image = tile_x + (threadIdx.x & 7u) < P.width && tile_y + ((threadIdx.x & 63u) >> 3) < P.height;
+    // the wave's pool, behind the object table
+    float4 *pool = rtx_smem + (SRC == kSrcLds ? table_lds_bytes(P.n_prims, P.n_lights) / 16u : 0u) +
+                   (threadIdx.x >> 6) * P.pool_entries;
+    uint32_t pool_used = 0;   // wave-uniform
 
+    uint32_t rays = 0;
     Counters<STATS> cnt;
     cnt.clear();
     const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
-    float *out = P.out_sum + 3ull * pixel;
     V3 sum = v3(0.0f, 0.0f, 0.0f);
-    if (P.accumulate) sum = v3(out[0], out[1], out[2]);
+    if (in_image && P.accumulate) {
+        const float *out = P.out_sum + 3ull * ((tile_y + ((threadIdx.x & 63u) >> 3)) * P.width + tile_x + (threadIdx.x & 7u));
+        sum = v3(out[0], out[1], out[2]);
+    }
+    const uint32_t last = P.sample_first + P.sample_count;
+    uint32_t next = in_image ? P.sample_first : last;   // own samples [next, end) are not started yet
+    uint32_t end = last;                                // own samples [end, last) were handed over
+    uint32_t head = kNoEntry;                           // entry of own sample `end`, the list's first
     Path p;
-    uint32_t s = P.sample_first;
-    const uint32_t s_end = P.sample_first + P.sample_count;
-    bool fresh = true;
-    while (s < s_end) {
-        if (fresh) {
-            uint4 w = draw_block(P, pixel, s, 0u);
-            camera_ray(P, pi, pj, u24(w.x), u24(w.y), p.o, p.d);
-            p.T = v3(1.0f, 1.0f, 1.0f);
-            p.L = v3(0.0f, 0.0f, 0.0f);
-            p.depth = 0;
-            fresh = false;
-            cnt.template add<C_SAMPLES>();
+    uint32_t s = 0;                                     // the sample being traced,
+    uint32_t job = threadIdx.x & 63u;                   // whose it is (bits 0-5) and its entry (6-15)
+    bool active = false;
+    for (;;) {
+        const uint32_t lane = threadIdx.x & 63u;
+        bool fresh = false;
+        if (!active && next < end) {
+            job = lane;
+            s = next++;
+            active = fresh = true;
         }
-        cnt.template add<C_RAYS>();
-        if constexpr (RECORD) rays += 1u;
-        float t;
-        int idx = closest_hit<SRC, STATS>(P, tab, p.o, p.d, t, cnt);
-        bool done;
-        if (idx < 0) {
-            p.L = p.L + cmul(p.T, bg);
-            done = true;
-        } else {
-            if constexpr (STATS) {
-                int kind = __float_as_int(tab.geom[3 * idx + 1].w) & 0xff;
-                cnt.template add<C_HIT_PLANE>(kind == kPlane);
-                cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
-                cnt.template add<C_HIT_BOX>(kind == kBox);
+        if (pool_used < P.pool_entries) {
+            unsigned long long idle = __ballot(!active);
+            while (idle != 0ull && pool_used < P.pool_entries) {
+                // every lane with unstarted samples is active here (it would have taken one above)
+                const uint32_t key = end - next;
+                const uint32_t most = wave_max(key);
+                if (most == 0u) break;
+                const int giver = __builtin_ctzll(__ballot(key == most));
+                const int taker = __builtin_ctzll(idle);
+                const uint32_t taken = (uint32_t)__builtin_amdgcn_readlane((int)end, giver) - 1u;
+                if ((int)lane == giver) {
+                    pool[pool_used].w = __uint_as_float(head);
+                    head = pool_used;
+                    end = taken;
+                }
+                if ((int)lane == taker) {
+                    job = (uint32_t)giver | (pool_used << 6);
+                    s = taken;
+                    active = fresh = true;
+                }
+                pool_used += 1u;
+                idle &= idle - 1ull;
             }
-            done = scatter<STATS, MANY_LIGHTS>(P, tab, p, idx, t, pixel, s, cnt);
         }
-        if (done) {
-            sum = sum + p.L;
-            s += 1;
-            fresh = true;
+        if (__ballot(active) == 0ull) break;
+        if (active) {
+            const uint32_t px = tile_x + (job & 7u), py = tile_y + ((job & 63u) >> 3);
+            const uint32_t pixel = py * P.width + px;
+            if (fresh) {
+                uint4 w = draw_block(P, pixel, s, 0u);
+                camera_ray(P, px, P.height - 1u - py, u24(w.x), u24(w.y), p.o, p.d);
+                p.T = v3(1.0f, 1.0f, 1.0f);
+                p.L = v3(0.0f, 0.0f, 0.0f);
+                p.depth = 0;
+                cnt.template add<C_SAMPLES>();
+            }
+            cnt.template add<C_RAYS>();
+            if constexpr (RECORD) rays += 1u;
+            float t;
+            int idx = closest_hit<SRC, STATS>(P, tab, p.o, p.d, t, cnt);
+            bool done;
+            if (idx < 0) {
+                p.L = p.L + cmul(p.T, bg);
+                done = true;
+            } else {
+                if constexpr (STATS) {
+                    int kind = __float_as_int(tab.geom[3 * idx + 1].w) & 0xff;
+                    cnt.template add<C_HIT_PLANE>(kind == kPlane);
+                    cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
+                    cnt.template add<C_HIT_BOX>(kind == kBox);
+                }
+                done = scatter<STATS, MANY_LIGHTS>(P, tab, p, idx, t, pixel, s, cnt);
+            }
+            if (done) {
+                if ((job & 63u) == lane) {
+                    sum = sum + p.L;
+                } else {
+                    float4 *e = pool + (job >> 6);
+                    e->x = p.L.x;
+                    e->y = p.L.y;
+                    e->z = p.L.z;
+                }
+                active = false;
+            }
         }
     }
-    out[0] = sum.x;
-    out[1] = sum.y;
-    out[2] = sum.z;
+    if (in_image) {
+        V3 total = sum;
+        for (uint32_t e = head; e != kNoEntry;) {   // samples end .. last-1 in this order
+            const float4 v = pool[e];
+            total = total + v3(v.x, v.y, v.z);
+            e = __float_as_uint(v.w);
+        }
+        float *out = P.out_sum + 3ull * ((tile_y + ((threadIdx.x & 63u) >> 3)) * P.width + tile_x + (threadIdx.x & 7u));
+        out[0] = total.x;
+        out[1] = total.y;
+        out[2] = total.z;
+    }
     if constexpr (RECORD) atomicMax(&P.tile_cost[tile], rays);
     if constexpr (STATS) {
 #pragma unroll
@@ -247,10 +329,19 @@ static void launch_megakernel_src(const RenderParams &p, bool stats, dim3 grid, 
     }
 }
 
-hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, hipStream_t stream)
+hipError_t launch_megakernel(const RenderParams &p0, int src, bool stats, hipStream_t stream)
 {
+    RenderParams p = p0;
     const dim3 grid = tile_grid(p);
-    const size_t lds = src == kSrcLds ? scene_lds_bytes(p.n_prims, p.n_lights) : 0;
+    // four workgroups share a CU's 160 KB of LDS: what the table (scan) or the traversal
+    // stacks (BVH, static) leave of 40 KB goes to the four waves' hand-over pools
+    const size_t table = src == kSrcLds ? scene_lds_bytes(p.n_prims, p.n_lights) : 0;
+    const size_t fixed = table + (src == kSrcBvh ? (size_t)kBvhStackSize * 256u * sizeof(int32_t) : 0u);
+    const size_t budget = 40u * 1024u;
+    p.pool_entries = fixed < budget ? (uint32_t)std::min<size_t>(kPoolEntriesMax, (budget - fixed) / (4u * sizeof(float4))) : 0u;
+    // diagnostic knob (tests, measurements): a smaller pool, 0 = no hand-over
+    if (const char *e = getenv("RTX_POOL_ENTRIES")) p.pool_entries = std::min<uint32_t>(p.pool_entries, (uint32_t)strtoul(e, nullptr, 10));
+    const size_t lds = table + (size_t)p.pool_entries * 4u * sizeof(float4);
     if (src == kSrcLds) launch_megakernel_src<kSrcLds>(p, stats, grid, lds, stream);
     else if (src == kSrcScalar) launch_megakernel_src<kSrcScalar>(p, stats, grid, lds, stream);
     else launch_megakernel_src<kSrcBvh>(p, stats, grid, lds, stream);

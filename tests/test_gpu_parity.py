@@ -449,6 +449,27 @@ def test_packed_division_has_the_bits_of_the_builtin_one():
     assert res.stdout.startswith("0 quotients differ"), res.stdout
 
 
+@pytest.mark.parametrize("accel", [_abi.ACCEL_BRUTE_LDS, _abi.ACCEL_BRUTE_SCALAR, _abi.ACCEL_BVH])
+def test_sample_hand_over_between_lanes_changes_no_bits(oracle, accel, monkeypatch):
+    """Lanes of the megakernel that run out of samples take over the last samples of slower
+    lanes through a pool in LDS; the owner adds them in index order.  With the pool switched
+    off, nearly empty (it runs out at once) and at its default size the image has the bits of
+    the oracle; lanes outside a ragged image take part too."""
+    sc = dielectric_scene(width=67, height=45, n_samples=37, ray_depth=12)
+    want = oracle.render(sc, seed=31, order=oracle.ORDER_FORWARD)
+    for entries in ("0", "1", "7", None):
+        if entries is None:
+            monkeypatch.delenv("RTX_POOL_ENTRIES", raising=False)
+        else:
+            monkeypatch.setenv("RTX_POOL_ENTRIES", entries)
+        with Renderer(seed=31, accel=accel) as r:
+            got = r.render(sc)
+            part = r.render(sc.replace(n_samples=2))       # fewer samples than lanes can share out
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), entries
+        assert np.array_equal(oracle.render(sc.replace(n_samples=2), seed=31, order=oracle.ORDER_FORWARD).view(np.uint32),
+                              part.view(np.uint32)), entries
+
+
 @pytest.mark.parametrize("accel", [_abi.ACCEL_BRUTE_LDS, _abi.ACCEL_BVH])
 def test_cost_ordered_dispatch_changes_no_bits(accel):
     """From 64 samples and 8192 tiles on the megakernel renders 8 samples first, sorts the tiles
