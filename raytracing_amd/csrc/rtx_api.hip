@@ -9,6 +9,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -333,6 +334,7 @@ int upload_scene(rtx_ctx *c)
     P.bvh.planes = reinterpret_cast<const int32_t *>(base + off_planes);
     P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / 2);
     P.bvh.n_planes = (uint32_t)bvh.planes.size();
+    P.bvh.stack_entries = (uint32_t)std::min(bvh.depth + 1, rtx::kBvhStackSize);
     {
         // objects outside the always-tested list are the leaves
         std::vector<char> listed(n, 0);

@@ -69,15 +69,23 @@ RTX_DEV bool slab_test(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint3
 constexpr float kBvhMaxMargin = 16384.0f;
 
 // BLOCK = threads per workgroup of the calling kernel (the stack array is sized for it).
+// DYN_STACK: the caller provides the stacks (B.stack_entries x BLOCK words of LDS: a tree of
+// depth d never holds more than d postponed nodes) instead of the static kBvhStackSize x BLOCK.
 //
 // The loop alternates two phases so that the expensive, kind-dependent object test is not
 // interleaved with the cheap node steps: every lane first descends until it holds a leaf (or
 // has finished), then all lanes holding a leaf test their object together.
-template <bool STATS, int BLOCK = 256>
-RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, float &best_t, Counters<STATS> &cnt)
+template <bool STATS, int BLOCK = 256, bool DYN_STACK = false>
+RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, float &best_t, Counters<STATS> &cnt,
+                            int32_t *dyn_stack = nullptr)
 {
-    __shared__ int32_t s_stack[kBvhStackSize * BLOCK];
-    int32_t *stack = s_stack + threadIdx.x;
+    int32_t *stack;
+    if constexpr (DYN_STACK) {
+        stack = dyn_stack + threadIdx.x;
+    } else {
+        __shared__ int32_t s_stack[kBvhStackSize * BLOCK];
+        stack = s_stack + threadIdx.x;
+    }
 
     const float ray_length = len(d);
     int best = -1;

@@ -40,6 +40,7 @@ struct BvhView {
     float far_slope;       // growth of the boxes per world unit the ray origin lies outside the grid
     const int32_t *planes; // objects that are tested for every ray
     uint32_t n_nodes, n_planes;
+    uint32_t stack_entries;   // postponed nodes a traversal can hold: the tree's depth + 1
     uint32_t leaves_identity;   // 1: every object in a leaf has the identity pose (kGeomIdentity)
 };
 

@@ -25,6 +25,18 @@ __host__ __device__ inline uint32_t table_lds_bytes(uint32_t n_prims, uint32_t n
     return (n_prims * 6u * (uint32_t)sizeof(float4) + n_lights * (uint32_t)sizeof(int32_t) + 15u) & ~15u;
 }
 size_t scene_lds_bytes(uint32_t n_prims, uint32_t n_lights) { return table_lds_bytes(n_prims, n_lights); }
+// dynamic LDS every kernel of this file starts with: the object table or the traversal stacks
+template <int SRC>
+__host__ __device__ inline uint32_t fixed_lds_bytes(const RenderParams &P)
+{
+    if (SRC == kSrcLds) return table_lds_bytes(P.n_prims, P.n_lights);
+    if (SRC == kSrcBvh) return P.bvh.stack_entries * 256u * (uint32_t)sizeof(int32_t);
+    return 0u;
+}
+static uint32_t fixed_lds_bytes(const RenderParams &P, int src)
+{
+    return src == kSrcLds ? fixed_lds_bytes<kSrcLds>(P) : src == kSrcBvh ? fixed_lds_bytes<kSrcBvh>(P) : 0u;
+}
 
 // copies the object table into LDS; every thread of the workgroup must call it
 RTX_DEV Table stage_table_lds(const RenderParams &P)
@@ -79,7 +91,9 @@ RTX_DEV bool lane_pixel(const RenderParams &P, uint32_t &px, uint32_t &py)
 template <int SRC, bool STATS>
 RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, float &t, Counters<STATS> &cnt)
 {
-    if constexpr (SRC == kSrcBvh) return closest_hit_bvh<STATS>(P.bvh, tab, o, d, t, cnt);
+    // BVH kernels of this file: the traversal stacks are the first part of the dynamic LDS
+    if constexpr (SRC == kSrcBvh)
+        return closest_hit_bvh<STATS, 256, true>(P.bvh, tab, o, d, t, cnt, reinterpret_cast<int32_t *>(rtx_smem));
     else return closest_hit_scan<true>(tab, o, d, t);
 }
 
@@ -115,9 +129,8 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
     if (P.tile_order) tile = P.tile_order[tile];
     const uint32_t tile_x = (tile % tiles_x) * 8u, tile_y = (tile / tiles_x) * 8u;
     const bool in_image = tile_x + (threadIdx.x & 7u) < P.width && tile_y + ((threadIdx.x & 63u) >> 3) < P.height;
-    // the wave's pool, behind the object table
-    float4 *pool = rtx_smem + (SRC == kSrcLds ? table_lds_bytes(P.n_prims, P.n_lights) / 16u : 0u) +
-                   (threadIdx.x >> 6) * P.pool_entries;
+    // the wave's pool, behind the object table (scan) or the traversal stacks (BVH)
+    float4 *pool = rtx_smem + fixed_lds_bytes<SRC>(P) / 16u + (threadIdx.x >> 6) * P.pool_entries;
     uint32_t pool_used = 0;   // wave-uniform
 
     uint32_t rays = 0;
@@ -334,14 +347,13 @@ hipError_t launch_megakernel(const RenderParams &p0, int src, bool stats, hipStr
     RenderParams p = p0;
     const dim3 grid = tile_grid(p);
     // four workgroups share a CU's 160 KB of LDS: what the table (scan) or the traversal
-    // stacks (BVH, static) leave of 40 KB goes to the four waves' hand-over pools
-    const size_t table = src == kSrcLds ? scene_lds_bytes(p.n_prims, p.n_lights) : 0;
-    const size_t fixed = table + (src == kSrcBvh ? (size_t)kBvhStackSize * 256u * sizeof(int32_t) : 0u);
+    // stacks (BVH) leave of 40 KB goes to the four waves' hand-over pools
+    const size_t fixed = fixed_lds_bytes(p, src);
     const size_t budget = 40u * 1024u;
     p.pool_entries = fixed < budget ? (uint32_t)std::min<size_t>(kPoolEntriesMax, (budget - fixed) / (4u * sizeof(float4))) : 0u;
     // diagnostic knob (tests, measurements): a smaller pool, 0 = no hand-over
     if (const char *e = getenv("RTX_POOL_ENTRIES")) p.pool_entries = std::min<uint32_t>(p.pool_entries, (uint32_t)strtoul(e, nullptr, 10));
-    const size_t lds = table + (size_t)p.pool_entries * 4u * sizeof(float4);
+    const size_t lds = fixed + (size_t)p.pool_entries * 4u * sizeof(float4);
     if (src == kSrcLds) launch_megakernel_src<kSrcLds>(p, stats, grid, lds, stream);
     else if (src == kSrcScalar) launch_megakernel_src<kSrcScalar>(p, stats, grid, lds, stream);
     else launch_megakernel_src<kSrcBvh>(p, stats, grid, lds, stream);
@@ -357,7 +369,7 @@ hipError_t launch_tile_order(const uint32_t *cost, uint32_t *order, uint32_t n_t
 hipError_t launch_primary(const RenderParams &p, const PrimaryParams &out, int src, hipStream_t stream)
 {
     dim3 grid = tile_grid(p), block(256);
-    size_t lds = src == kSrcLds ? scene_lds_bytes(p.n_prims, p.n_lights) : 0;
+    size_t lds = fixed_lds_bytes(p, src);
     if (src == kSrcLds) hipLaunchKernelGGL((k_primary<kSrcLds>), grid, block, lds, stream, p, out);
     else if (src == kSrcScalar) hipLaunchKernelGGL((k_primary<kSrcScalar>), grid, block, lds, stream, p, out);
     else hipLaunchKernelGGL((k_primary<kSrcBvh>), grid, block, lds, stream, p, out);
