@@ -13,9 +13,12 @@
  * keeps no caller pointer.  No function aborts or throws: each returns
  * RTX_OK (0) or a negative rtx_status, and rtx_last_error() gives a message for
  * the calling thread's last failure.  One rtx_ctx belongs to one host thread at
- * a time and drives one GPU.  Renders of one context share device scratch (path
- * state, tile order): give them one stream, or wait for one to end before the
- * next starts on another stream.
+ * a time.  It drives one GPU, or -- rtx_opts.n_devices > 1 -- several GPUs of one
+ * node from that one thread: the sample loop is split over them and their sums are
+ * added on the devices (see rtx_opts).  Renders of one context share device scratch
+ * (path state, tile order): give them one stream, or wait for one to end before the
+ * next starts on another stream; rtx_set_scene waits for the context's device(s) to
+ * go idle before it overwrites the scene a render may still be reading.
  */
 #ifndef RTX_H
 #define RTX_H
@@ -89,14 +92,36 @@ typedef enum {
 #define RTX_MAX_LDS_PRIMS 512u   /* largest object table RTX_ACCEL_BRUTE_LDS accepts */
 #define RTX_AUTO_BRUTE_MAX 6u    /* RTX_ACCEL_AUTO: most non-plane objects the linear scan is chosen for */
 
+/* How the per-GPU radiance sums of a multi-GPU context are added. */
+typedef enum {
+    RTX_REDUCE_P2P = 0,  /* hand-written slice reduce over peer access (xGMI): GPU g adds slice g of
+                            every GPU's buffer in device order, divides, and sends its slice to the host */
+    RTX_REDUCE_RCCL = 1  /* ncclAllReduce(sum) from librccl.so, one communicator rank per GPU in this
+                            process; GPU 0 divides and sends the image to the host */
+} rtx_reduce;
+
+#define RTX_MAX_DEVICES 16
+
 typedef struct rtx_opts {
     uint64_t seed;
     uint32_t mode;           /* rtx_mode */
     uint32_t accel;          /* rtx_accel */
     uint32_t rng_mode;       /* rtx_rng */
     uint32_t const_words[4];
-    int32_t device;          /* HIP device ordinal; -1 = the current device */
+    int32_t device;          /* HIP device ordinal; -1 = the current device (used when n_devices <= 1) */
     uint32_t collect_stats;  /* 1 = count path events (slower kernels; see rtx_get_stats) */
+    /* Several GPUs behind one context.  The loop over sample steps (src/main.rs:14) is cut into
+     * n_devices contiguous ranges, GPU g renders range g of every pixel into its own sum buffer on
+     * its own stream, and the sums are added as `reduce` says -- all inside rtx_render,
+     * rtx_render_bytes and rtx_progress_*, which keep their signatures.  The image depends on
+     * n_devices only through the order of these n_devices additions per value.
+     * n_devices 0 or 1: one GPU, `device`.  devices = NULL: ordinals 0 .. n_devices-1.  An ordinal
+     * may repeat (several ranges on one GPU; RTX_REDUCE_P2P only).  Entry points that take DEVICE
+     * pointers (rtx_render_samples, rtx_accumulate_samples, rtx_divide, rtx_tonemap_bytes) and
+     * rtx_primary run on devices[0] alone. */
+    int32_t n_devices;
+    uint32_t reduce;         /* rtx_reduce */
+    const int32_t *devices;  /* n_devices HIP ordinals, copied by rtx_create */
 } rtx_opts;
 
 /* Path events of the most recent render call, counted on the device when
@@ -203,12 +228,15 @@ int rtx_last_kernel_ms(rtx_ctx *ctx, float *ms);
 /* Number of lights derived from the current scene, and their object indices. */
 int rtx_get_lights(rtx_ctx *ctx, int32_t *indices, int32_t capacity);
 
+/* Number of GPUs the context drives (1 unless rtx_opts.n_devices asked for more). */
+int rtx_device_count(rtx_ctx *ctx);
+
 /* Message for the calling thread's most recent error ("" if none). */
 const char *rtx_last_error(void);
 
 /* ABI version of this header: bumped on any layout or signature change. */
 uint32_t rtx_abi_version(void);
-#define RTX_ABI_VERSION 2u
+#define RTX_ABI_VERSION 3u
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,5 @@
 //! Raw bindings to `librtx.so`, declaration by declaration after `include/rtx.h`
-//! (ABI version 2), plus `Context`, a small owner type for the context pointer.
+//! (ABI version 3), plus `Context`, a small owner type for the context pointer.
 //!
 //! Written against the header; it could not be compiled where it was written (no Rust
 //! toolchain there).  `tests/test_abi.py` checks that the functions and struct fields named
@@ -8,7 +8,7 @@
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTX_ABI_VERSION: u32 = 2;
+pub const RTX_ABI_VERSION: u32 = 3;
 
 pub const RTX_OK: c_int = 0;
 pub const RTX_ERR_INVALID_ARG: c_int = -1;
@@ -32,6 +32,9 @@ pub const RTX_ACCEL_BRUTE_SCALAR: u32 = 2;
 pub const RTX_ACCEL_BVH: u32 = 3;
 pub const RTX_RNG_PHILOX: u32 = 0;
 pub const RTX_RNG_CONST: u32 = 1;
+pub const RTX_REDUCE_P2P: u32 = 0;
+pub const RTX_REDUCE_RCCL: u32 = 1;
+pub const RTX_MAX_DEVICES: usize = 16;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -63,7 +66,7 @@ pub struct rtx_scene {
 }
 
 #[repr(C)]
-#[derive(Clone, Copy, Debug, Default)]
+#[derive(Clone, Copy, Debug)]
 pub struct rtx_opts {
     pub seed: u64,
     pub mode: u32,
@@ -72,6 +75,18 @@ pub struct rtx_opts {
     pub const_words: [u32; 4],
     pub device: i32,
     pub collect_stats: u32,
+    pub n_devices: i32,
+    pub reduce: u32,
+    pub devices: *const i32,
+}
+
+impl Default for rtx_opts {
+    /// One GPU (the current device), megakernel, automatic acceleration structure, seed 1.
+    fn default() -> Self {
+        rtx_opts { seed: 1, mode: RTX_MODE_MEGAKERNEL, accel: RTX_ACCEL_AUTO, rng_mode: RTX_RNG_PHILOX,
+                   const_words: [0; 4], device: -1, collect_stats: 0, n_devices: 0, reduce: RTX_REDUCE_P2P,
+                   devices: std::ptr::null() }
+    }
 }
 
 #[repr(C)]
@@ -114,6 +129,7 @@ extern "C" {
     pub fn rtx_get_stats(ctx: *mut rtx_ctx, out: *mut rtx_stats) -> c_int;
     pub fn rtx_last_kernel_ms(ctx: *mut rtx_ctx, ms: *mut f32) -> c_int;
     pub fn rtx_get_lights(ctx: *mut rtx_ctx, indices: *mut i32, capacity: i32) -> c_int;
+    pub fn rtx_device_count(ctx: *mut rtx_ctx) -> c_int;
     pub fn rtx_last_error() -> *const c_char;
     pub fn rtx_abi_version() -> u32;
 }
@@ -123,12 +139,18 @@ pub fn last_error() -> String {
     unsafe { CStr::from_ptr(rtx_last_error()).to_string_lossy().into_owned() }
 }
 
-/// Owner of an `rtx_ctx`: one GPU, one host thread at a time.
+/// Owner of an `rtx_ctx`: one host thread at a time; one GPU, or `opts.n_devices` of them.
 pub struct Context {
     raw: *mut rtx_ctx,
 }
 
 impl Context {
+    /// All `n` GPUs 0..n of the node behind one context: `render` splits the samples over them.
+    pub fn with_gpus(n: i32, seed: u64) -> Result<Context, String> {
+        let opts = rtx_opts { seed, n_devices: n, ..Default::default() };
+        Context::new(&opts)
+    }
+
     pub fn new(opts: &rtx_opts) -> Result<Context, String> {
         unsafe {
             if rtx_abi_version() != RTX_ABI_VERSION {

@@ -12,6 +12,7 @@ DIFFUSE, METALLIC, DIELECTRIC = 0, 1, 2
 MODE_MEGAKERNEL, MODE_WAVEFRONT = 0, 1
 ACCEL_AUTO, ACCEL_BRUTE_LDS, ACCEL_BRUTE_SCALAR, ACCEL_BVH = 0, 1, 2, 3
 RNG_PHILOX, RNG_CONST = 0, 1
+REDUCE_P2P, REDUCE_RCCL = 0, 1
 
 RTX_OK = 0
 RTX_ERR_INVALID_ARG = -1
@@ -21,8 +22,9 @@ RTX_ERR_NO_SCENE = -4
 RTX_ERR_UNSUPPORTED = -5
 RTX_ERR_NO_MEMORY = -6
 
-RTX_ABI_VERSION = 2
+RTX_ABI_VERSION = 3
 RTX_MAX_LDS_PRIMS = 512
+RTX_MAX_DEVICES = 16
 
 
 class rtx_prim(C.Structure):
@@ -63,6 +65,9 @@ class rtx_opts(C.Structure):
         ("const_words", C.c_uint32 * 4),
         ("device", C.c_int32),
         ("collect_stats", C.c_uint32),
+        ("n_devices", C.c_int32),
+        ("reduce", C.c_uint32),
+        ("devices", C.POINTER(C.c_int32)),
     ]
 
 

@@ -3,6 +3,8 @@
 // Options after the two positional arguments override what the scene file says, so the
 // benchmark configurations can reuse one scene file:
 //   --size W H   --spp N   --depth N   --seed N   --mode megakernel|wavefront
+//   --gpus N              split the samples over GPUs 0..N-1 of the node (sums added on the GPUs)
+//   --reduce p2p|rccl     how: peer-access slice reduce (default) or RCCL all-reduce
 // Output stage:
 //   --device-tonemap      tone map and quantise on the GPU; only bytes come back
 // Progressive rendering (the image equals the one-shot render bit for bit):
@@ -38,6 +40,8 @@ int main(int argc, char **argv)
         else if (a == "--depth") { need(1); depth = std::atol(argv[++i]); }
         else if (a == "--seed") { need(1); opts.seed = std::strtoull(argv[++i], nullptr, 10); }
         else if (a == "--mode") { need(1); opts.mode = std::string(argv[++i]) == "wavefront" ? RTX_MODE_WAVEFRONT : RTX_MODE_MEGAKERNEL; }
+        else if (a == "--gpus") { need(1); opts.n_devices = (int32_t)std::atol(argv[++i]); }
+        else if (a == "--reduce") { need(1); opts.reduce = std::string(argv[++i]) == "rccl" ? RTX_REDUCE_RCCL : RTX_REDUCE_P2P; }
         else if (a == "--chunk") { need(1); chunk = std::atol(argv[++i]); }
         else if (a == "--stop-after") { need(1); stop_after = std::atol(argv[++i]); }
         else if (a == "--checkpoint") { need(1); checkpoint = argv[++i]; }

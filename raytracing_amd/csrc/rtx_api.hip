@@ -1,4 +1,4 @@
-// rtx_api.hip -- the C ABI of include/rtx.h: context, scene upload, launches.
+// rtx_api.hip -- the C ABI of include/rtx.h: context, scene upload, launches, multi-GPU split.
 //
 // Replaces the call `render(&mut scene)` of src/main.rs:38 and the Scene hand-over of
 // src/main.rs:37; the lights list is derived here by the rule of src/parser.rs:69-89.
@@ -9,27 +9,28 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
-#include <string>
 #include <vector>
 
 namespace {
 
-thread_local std::string g_last_error;
+// fixed storage: reporting an error must not allocate (it may be reporting an allocation failure)
+thread_local char g_last_error[512] = "";
 
 int fail(int code, const char *fmt, ...)
 {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
     va_end(ap);
-    g_last_error = buf;
     return code;
 }
 
@@ -40,6 +41,20 @@ int fail(int code, const char *fmt, ...)
             return fail(e_ == hipErrorOutOfMemory ? RTX_ERR_NO_MEMORY : RTX_ERR_DEVICE, "%s: %s",  \
                         #expr, hipGetErrorString(e_));                                             \
     } while (0)
+
+// No exception may cross the C boundary: every entry point that can allocate host memory runs its
+// body through this.
+template <class F>
+int guarded(const char *what, F &&body) noexcept
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail(RTX_ERR_NO_MEMORY, "%s: out of host memory", what);
+    } catch (...) {
+        return fail(RTX_ERR_DEVICE, "%s: unexpected exception", what);
+    }
+}
 
 struct DeviceGuard {
     int prev = -1;
@@ -54,6 +69,99 @@ struct DeviceGuard {
         if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
+
+// ------------------------------------------------------------------ RCCL, loaded on demand
+// Only a context created with RTX_REDUCE_RCCL touches librccl.so; the symbols are resolved at run
+// time so that librtx.so itself depends on the HIP runtime alone (a process that already holds an
+// RCCL -- PyTorch brings its own -- keeps using that one: dlopen finds it by its soname).
+struct Rccl {
+    void *handle = nullptr;
+    int (*CommInitAll)(void **comms, int ndev, const int *devlist) = nullptr;
+    int (*CommDestroy)(void *comm) = nullptr;
+    int (*AllReduce)(const void *send, void *recv, size_t count, int dtype, int op, void *comm, hipStream_t s) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;   // ncclDataType_t / ncclRedOp_t values of nccl.h
+Rccl g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.handle) return RTX_OK;
+    void *h = nullptr;
+    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (h) break;
+    }
+    if (!h) return fail(RTX_ERR_UNSUPPORTED, "RTX_REDUCE_RCCL: cannot load librccl.so (%s)", dlerror());
+    Rccl r;
+    r.handle = h;
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!r.CommInitAll || !r.CommDestroy || !r.AllReduce || !r.GroupStart || !r.GroupEnd || !r.GetErrorString)
+        return fail(RTX_ERR_UNSUPPORTED, "RTX_REDUCE_RCCL: librccl.so lacks an expected symbol");
+    g_rccl = r;
+    return RTX_OK;
+}
+#define RCCL_TRY(expr)                                                                             \
+    do {                                                                                           \
+        int e_ = (expr);                                                                           \
+        if (e_ != 0) return fail(RTX_ERR_DEVICE, "%s: %s", #expr, g_rccl.GetErrorString(e_));      \
+    } while (0)
+
+// ------------------------------------------------------------------ multi-GPU slice reduce
+// GPU g of G owns floats [first, first + count) of the image: it adds that slice of every GPU's
+// sum buffer in device order (so the result does not depend on which GPU does the adding), reading
+// the other GPUs' buffers over peer access, and optionally divides by the sample count.
+struct ReduceSources {
+    const float *src[RTX_MAX_DEVICES];
+    int n;
+};
+__global__ void __launch_bounds__(256) k_reduce_slices(ReduceSources S, uint64_t first, uint64_t count, float divisor,
+                                                       int divide, float *out)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t tid = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x;
+    // `first` is a multiple of 4 floats and the buffers are 256-byte aligned: 16-byte accesses
+    const uint64_t n4 = count / 4u;
+    for (uint64_t i = tid; i < n4; i += stride) {
+        float4 acc = reinterpret_cast<const float4 *>(S.src[0] + first)[i];
+        for (int d = 1; d < S.n; ++d) {
+            const float4 v = reinterpret_cast<const float4 *>(S.src[d] + first)[i];
+            acc.x = acc.x + v.x;
+            acc.y = acc.y + v.y;
+            acc.z = acc.z + v.z;
+            acc.w = acc.w + v.w;
+        }
+        if (divide) {
+            acc.x = acc.x / divisor;
+            acc.y = acc.y / divisor;
+            acc.z = acc.z / divisor;
+            acc.w = acc.w / divisor;
+        }
+        reinterpret_cast<float4 *>(out)[i] = acc;
+    }
+    for (uint64_t i = 4u * n4 + tid; i < count; i += stride) {
+        float acc = S.src[0][first + i];
+        for (int d = 1; d < S.n; ++d) acc = acc + S.src[d][first + i];
+        out[i] = divide ? acc / divisor : acc;
+    }
+}
+
+// Every path is cut before its first intersection when ray_depth is 0 (src/trace.rs:12-14): each
+// sample adds (0, 0, 0) to its pixel.  (-0) + 0 = +0, so a continued sum is not simply kept.
+__global__ void __launch_bounds__(256) k_add_zero_samples(float *sum, uint64_t n, int accumulate, int any_samples)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const float s = accumulate ? sum[i] : 0.0f;
+        sum[i] = any_samples ? s + 0.0f : s;
+    }
+}
 
 }  // namespace
 
@@ -75,6 +183,8 @@ struct rtx_ctx {
     size_t d_image_floats = 0;
     uint8_t *d_bytes = nullptr;   // tone-mapped image
     size_t d_bytes_size = 0;
+    void *d_primary = nullptr;    // outputs of the primary pass
+    size_t d_primary_bytes = 0;
     // progressive rendering: d_image holds the sum of samples [0, progress_done)
     bool progress_active = false;
     uint32_t progress_done = 0;
@@ -82,14 +192,33 @@ struct rtx_ctx {
     size_t d_wavefront_bytes = 0;
     uint32_t *d_tiles = nullptr;  // cost and dispatch order of the 8x8 tiles, n_tiles words each
     size_t d_tiles_words = 0;
+    uint32_t pool_limit = rtx::kPoolEntriesMax;   // cap of the megakernel's hand-over pool (RTX_POOL_ENTRIES)
     unsigned long long *d_stats = nullptr;
     rtx_stats stats{};
     bool stats_valid = false;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
+    // A multi-GPU context is its own worker 0 and owns one more context per further GPU.  Every
+    // worker renders its share of the samples into its d_image on its own stream.
+    std::vector<rtx_ctx *> peers;
+    hipStream_t stream = nullptr;   // workers of a multi-GPU context: their own stream
+    hipEvent_t ev_done = nullptr;   // this worker's share of a render is complete
+    float *d_reduced = nullptr;     // P2P: this worker's slice of the summed image; RCCL: the whole of it
+    size_t d_reduced_floats = 0;
+    void *comm = nullptr;           // RCCL communicator rank of this worker
 };
 
 namespace {
+
+// the workers of a context: itself, then its peers
+std::vector<rtx_ctx *> workers_of(rtx_ctx *c)
+{
+    std::vector<rtx_ctx *> w;
+    w.reserve(1 + c->peers.size());
+    w.push_back(c);
+    for (rtx_ctx *p : c->peers) w.push_back(p);
+    return w;
+}
 
 void free_scene(rtx_ctx *c)
 {
@@ -203,7 +332,15 @@ int validate_scene(const rtx_scene *s)
     return RTX_OK;
 }
 
-int upload_scene(rtx_ctx *c)
+// The device scene block as the host builds it, once per rtx_set_scene; every worker of the
+// context uploads the same bytes and points its kernel parameters into its own copy.
+struct SceneBlock {
+    std::vector<unsigned char> bytes;
+    size_t off_mat = 0, off_lights = 0, off_lbound = 0, off_nodes = 0, off_planes = 0;
+    rtx::RenderParams params{};   // everything but the device pointers
+};
+
+void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
 {
     const size_t n = c->prims.size();
     const size_t nl = c->lights.size();
@@ -219,7 +356,8 @@ int upload_scene(rtx_ctx *c)
     const size_t plane_bytes = align16(bvh.planes.size() * sizeof(int32_t));
 
     const size_t total = geom_bytes + mat_bytes + light_bytes + lbound_bytes + node_bytes + plane_bytes + 16;
-    std::vector<unsigned char> host(total, 0);
+    blk.bytes.assign(total, 0);
+    std::vector<unsigned char> &host = blk.bytes;
     float4 *geom = reinterpret_cast<float4 *>(host.data());
     float4 *mat = reinterpret_cast<float4 *>(host.data() + geom_bytes);
     int32_t *lights = reinterpret_cast<int32_t *>(host.data() + geom_bytes + mat_bytes);
@@ -288,28 +426,19 @@ int upload_scene(rtx_ctx *c)
         lbound[2 * i + 0] = make_float4(p.position[0], p.position[1], p.position[2], r2f);
         lbound[2 * i + 1] = make_float4(slackf, 0.0f, 0.0f, 0.0f);
     }
-    size_t off_nodes = off_lbound + lbound_bytes;
-    size_t off_planes = off_nodes + node_bytes;
+    const size_t off_nodes = off_lbound + lbound_bytes;
+    const size_t off_planes = off_nodes + node_bytes;
     if (!bvh.nodes.empty()) std::memcpy(host.data() + off_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(uint4));
     if (!bvh.planes.empty())
         std::memcpy(host.data() + off_planes, bvh.planes.data(), bvh.planes.size() * sizeof(int32_t));
+    blk.off_mat = geom_bytes;
+    blk.off_lights = geom_bytes + mat_bytes;
+    blk.off_lbound = off_lbound;
+    blk.off_nodes = off_nodes;
+    blk.off_planes = off_planes;
 
-    if (c->d_scene_bytes < total) {
-        if (c->d_scene) (void)hipFree(c->d_scene);
-        c->d_scene = nullptr;
-        c->d_scene_bytes = 0;
-        HIP_TRY(hipMalloc(&c->d_scene, total));
-        c->d_scene_bytes = total;
-    }
-    HIP_TRY(hipMemcpy(c->d_scene, host.data(), total, hipMemcpyHostToDevice));
-
-    unsigned char *base = static_cast<unsigned char *>(c->d_scene);
-    rtx::RenderParams &P = c->params;
+    rtx::RenderParams &P = blk.params;
     std::memset(&P, 0, sizeof(P));
-    P.geom = reinterpret_cast<const float4 *>(base);
-    P.mat = reinterpret_cast<const float4 *>(base + geom_bytes);
-    P.lights = reinterpret_cast<const int32_t *>(base + geom_bytes + mat_bytes);
-    P.light_bounds = reinterpret_cast<const float4 *>(base + off_lbound);
     P.n_prims = (uint32_t)n;
     P.n_lights = (uint32_t)nl;
     const rtx_scene &s = c->scene;
@@ -326,12 +455,10 @@ int upload_scene(rtx_ctx *c)
     P.rng_const = c->opts.rng_mode == RTX_RNG_CONST ? 1u : 0u;
     P.stop_on_zero = scene_is_tame(c->scene, c->prims) ? 1u : 0u;
     std::memcpy(P.const_words, c->opts.const_words, sizeof(P.const_words));
-    P.bvh.nodes = reinterpret_cast<const uint4 *>(base + off_nodes);
     std::memcpy(P.bvh.grid_base, bvh.grid_base, sizeof(P.bvh.grid_base));
     std::memcpy(P.bvh.grid_inv_step, bvh.grid_inv_step, sizeof(P.bvh.grid_inv_step));
     std::memcpy(P.bvh.grid_step, bvh.grid_step, sizeof(P.bvh.grid_step));
     P.bvh.far_slope = bvh.far_slope;
-    P.bvh.planes = reinterpret_cast<const int32_t *>(base + off_planes);
     P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / 2);
     P.bvh.n_planes = (uint32_t)bvh.planes.size();
     P.bvh.stack_entries = (uint32_t)std::min(bvh.depth + 1, rtx::kBvhStackSize);
@@ -343,6 +470,31 @@ int upload_scene(rtx_ctx *c)
         for (size_t i = 0; i < n; ++i) all = all && (listed[i] || is_identity_pose(c->prims[i]));
         P.bvh.leaves_identity = all ? 1u : 0u;
     }
+}
+
+// one worker's copy of the block; the worker's device must be current
+int upload_scene_block(rtx_ctx *w, const SceneBlock &blk)
+{
+    // a render of this worker may still be reading the block that is about to be overwritten
+    HIP_TRY(hipDeviceSynchronize());
+    const size_t total = blk.bytes.size();
+    if (w->d_scene_bytes < total) {
+        if (w->d_scene) (void)hipFree(w->d_scene);
+        w->d_scene = nullptr;
+        w->d_scene_bytes = 0;
+        HIP_TRY(hipMalloc(&w->d_scene, total));
+        w->d_scene_bytes = total;
+    }
+    HIP_TRY(hipMemcpy(w->d_scene, blk.bytes.data(), total, hipMemcpyHostToDevice));
+    unsigned char *base = static_cast<unsigned char *>(w->d_scene);
+    rtx::RenderParams &P = w->params;
+    P = blk.params;
+    P.geom = reinterpret_cast<const float4 *>(base);
+    P.mat = reinterpret_cast<const float4 *>(base + blk.off_mat);
+    P.lights = reinterpret_cast<const int32_t *>(base + blk.off_lights);
+    P.light_bounds = reinterpret_cast<const float4 *>(base + blk.off_lbound);
+    P.bvh.nodes = reinterpret_cast<const uint4 *>(base + blk.off_nodes);
+    P.bvh.planes = reinterpret_cast<const int32_t *>(base + blk.off_planes);
     return RTX_OK;
 }
 
@@ -365,6 +517,17 @@ int ensure_bytes(rtx_ctx *c, size_t n)
     c->d_bytes_size = 0;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_bytes), n));
     c->d_bytes_size = n;
+    return RTX_OK;
+}
+
+int ensure_reduced(rtx_ctx *c, size_t floats)
+{
+    if (c->d_reduced_floats >= floats) return RTX_OK;
+    if (c->d_reduced) (void)hipFree(c->d_reduced);
+    c->d_reduced = nullptr;
+    c->d_reduced_floats = 0;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_reduced), floats * sizeof(float)));
+    c->d_reduced_floats = floats;
     return RTX_OK;
 }
 
@@ -401,57 +564,170 @@ void stats_from_counters(const rtx_ctx *c, const unsigned long long *v, rtx_stat
     }
 }
 
+void add_stats(rtx_stats &a, const rtx_stats &b)
+{
+    static_assert(sizeof(rtx_stats) % sizeof(uint64_t) == 0, "rtx_stats is an array of 64-bit counters");
+    uint64_t *pa = reinterpret_cast<uint64_t *>(&a);
+    const uint64_t *pb = reinterpret_cast<const uint64_t *>(&b);
+    for (size_t i = 0; i < sizeof(rtx_stats) / sizeof(uint64_t); ++i) pa[i] += pb[i];
+}
+
+// contiguous, balanced cut of `count` items into `parts`: the first count % parts get one more
+void split_range(uint64_t count, uint32_t parts, uint32_t part, uint64_t &first, uint64_t &len)
+{
+    const uint64_t base = count / parts, extra = count % parts;
+    first = part * base + std::min<uint64_t>(part, extra);
+    len = base + (part < extra ? 1u : 0u);
+}
+// the slice of the image worker g of G reduces: boundaries at multiples of 4 floats
+void image_slice(uint64_t floats, uint32_t G, uint32_t g, uint64_t &first, uint64_t &len)
+{
+    const uint64_t quads = (floats + 3u) / 4u;
+    uint64_t qf, ql;
+    split_range(quads, G, g, qf, ql);
+    first = std::min(floats, qf * 4u);
+    len = std::min(floats, (qf + ql) * 4u) - first;
+}
+
+int create_worker(rtx_ctx **out, const rtx_opts *opts, int dev, bool own_stream)
+{
+    rtx_ctx *c = new (std::nothrow) rtx_ctx();
+    if (!c) return fail(RTX_ERR_NO_MEMORY, "out of host memory");
+    c->opts = *opts;
+    c->opts.devices = nullptr;
+    c->device = dev;
+    // diagnostic knob (tests, measurements), read once: a smaller hand-over pool, 0 = no hand-over
+    if (const char *e = getenv("RTX_POOL_ENTRIES")) {
+        char *end = nullptr;
+        const unsigned long v = strtoul(e, &end, 10);
+        if (end != e && *end == '\0') c->pool_limit = (uint32_t)std::min<unsigned long>(v, rtx::kPoolEntriesMax);
+    }
+    DeviceGuard g(dev);
+    if (!g.ok) { delete c; return fail(RTX_ERR_DEVICE, "cannot select device %d", dev); }
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_stats), rtx::C_COUNT * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
+    if (e == hipSuccess && own_stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        rtx_destroy(c);
+        return fail(RTX_ERR_DEVICE, "context set-up on device %d: %s", dev, hipGetErrorString(e));
+    }
+    *out = c;
+    return RTX_OK;
+}
+
+void destroy_worker(rtx_ctx *c)
+{
+    DeviceGuard g(c->device);
+    (void)hipDeviceSynchronize();
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    free_scene(c);
+    if (c->d_image) (void)hipFree(c->d_image);
+    if (c->d_bytes) (void)hipFree(c->d_bytes);
+    if (c->d_primary) (void)hipFree(c->d_primary);
+    if (c->d_reduced) (void)hipFree(c->d_reduced);
+    if (c->d_wavefront) (void)hipFree(c->d_wavefront);
+    if (c->d_tiles) (void)hipFree(c->d_tiles);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
+    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
 }  // namespace
 
 extern "C" {
 
 uint32_t rtx_abi_version(void) { return RTX_ABI_VERSION; }
 
-const char *rtx_last_error(void) { return g_last_error.c_str(); }
+const char *rtx_last_error(void) { return g_last_error; }
 
 int rtx_create(rtx_ctx **out, const rtx_opts *opts)
 {
     if (!out || !opts) return fail(RTX_ERR_INVALID_ARG, "rtx_create: null argument");
     *out = nullptr;
-    if (opts->mode > RTX_MODE_WAVEFRONT) return fail(RTX_ERR_INVALID_ARG, "unknown mode %u", opts->mode);
-    if (opts->accel > RTX_ACCEL_BVH) return fail(RTX_ERR_INVALID_ARG, "unknown accel %u", opts->accel);
-    if (opts->rng_mode > RTX_RNG_CONST) return fail(RTX_ERR_INVALID_ARG, "unknown rng_mode %u", opts->rng_mode);
-    int n_dev = 0;
-    HIP_TRY(hipGetDeviceCount(&n_dev));
-    if (n_dev <= 0) return fail(RTX_ERR_DEVICE, "no HIP device visible");
-    int dev = opts->device;
-    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
-    if (dev >= n_dev) return fail(RTX_ERR_INVALID_ARG, "device %d out of range (%d visible)", dev, n_dev);
-    rtx_ctx *c = new (std::nothrow) rtx_ctx();
-    if (!c) return fail(RTX_ERR_NO_MEMORY, "out of host memory");
-    c->opts = *opts;
-    c->device = dev;
-    DeviceGuard g(dev);
-    if (!g.ok) { delete c; return fail(RTX_ERR_DEVICE, "cannot select device %d", dev); }
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_stats), rtx::C_COUNT * sizeof(unsigned long long));
-    if (e == hipSuccess) e = hipEventCreate(&c->ev_start);
-    if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
-    if (e != hipSuccess) {
-        rtx_destroy(c);
-        return fail(RTX_ERR_DEVICE, "context set-up: %s", hipGetErrorString(e));
-    }
-    *out = c;
-    return RTX_OK;
+    return guarded("rtx_create", [&]() -> int {
+        if (opts->mode > RTX_MODE_WAVEFRONT) return fail(RTX_ERR_INVALID_ARG, "unknown mode %u", opts->mode);
+        if (opts->accel > RTX_ACCEL_BVH) return fail(RTX_ERR_INVALID_ARG, "unknown accel %u", opts->accel);
+        if (opts->rng_mode > RTX_RNG_CONST) return fail(RTX_ERR_INVALID_ARG, "unknown rng_mode %u", opts->rng_mode);
+        if (opts->reduce > RTX_REDUCE_RCCL) return fail(RTX_ERR_INVALID_ARG, "unknown reduce %u", opts->reduce);
+        if (opts->n_devices < 0 || opts->n_devices > RTX_MAX_DEVICES)
+            return fail(RTX_ERR_INVALID_ARG, "n_devices %d out of range (at most %d)", opts->n_devices, RTX_MAX_DEVICES);
+        int n_dev = 0;
+        HIP_TRY(hipGetDeviceCount(&n_dev));
+        if (n_dev <= 0) return fail(RTX_ERR_DEVICE, "no HIP device visible");
+        const bool multi = opts->n_devices > 1 || (opts->n_devices == 1 && opts->reduce == RTX_REDUCE_RCCL);
+        std::vector<int> devs;
+        if (opts->n_devices <= 1 && !(opts->n_devices == 1 && opts->devices)) {
+            int dev = opts->device;
+            if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+            devs.push_back(dev);
+        } else {
+            for (int i = 0; i < opts->n_devices; ++i) devs.push_back(opts->devices ? opts->devices[i] : i);
+        }
+        for (int d : devs)
+            if (d < 0 || d >= n_dev) return fail(RTX_ERR_INVALID_ARG, "device %d out of range (%d visible)", d, n_dev);
+        if (multi && opts->reduce == RTX_REDUCE_RCCL) {
+            for (size_t i = 0; i < devs.size(); ++i)
+                for (size_t j = 0; j < i; ++j)
+                    if (devs[i] == devs[j])
+                        return fail(RTX_ERR_INVALID_ARG, "RTX_REDUCE_RCCL needs distinct devices (%d is listed twice)", devs[i]);
+            int rc = load_rccl();
+            if (rc != RTX_OK) return rc;
+        }
+        rtx_ctx *c = nullptr;
+        int rc = create_worker(&c, opts, devs[0], multi);
+        if (rc != RTX_OK) return rc;
+        for (size_t i = 1; i < devs.size(); ++i) {
+            rtx_ctx *p = nullptr;
+            rc = create_worker(&p, opts, devs[i], true);
+            if (rc != RTX_OK) { rtx_destroy(c); return rc; }
+            c->peers.push_back(p);
+        }
+        if (devs.size() > 1 && opts->reduce == RTX_REDUCE_P2P) {
+            // every GPU reads its slice from every other GPU's buffer
+            for (size_t i = 0; i < devs.size(); ++i) {
+                DeviceGuard g(devs[i]);
+                for (size_t j = 0; j < devs.size(); ++j) {
+                    if (devs[i] == devs[j]) continue;
+                    int can = 0;
+                    hipError_t e = hipDeviceCanAccessPeer(&can, devs[i], devs[j]);
+                    if (e == hipSuccess && can) {
+                        e = hipDeviceEnablePeerAccess(devs[j], 0);
+                        if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+                    }
+                    if (e != hipSuccess || !can) {
+                        rtx_destroy(c);
+                        return fail(RTX_ERR_UNSUPPORTED, "device %d cannot read device %d's memory (no peer access); use RTX_REDUCE_RCCL",
+                                    devs[i], devs[j]);
+                    }
+                }
+            }
+        }
+        if (multi && opts->reduce == RTX_REDUCE_RCCL) {
+            std::vector<void *> comms(devs.size(), nullptr);
+            int e = g_rccl.CommInitAll(comms.data(), (int)devs.size(), devs.data());
+            if (e != 0) {
+                rtx_destroy(c);
+                return fail(RTX_ERR_DEVICE, "ncclCommInitAll: %s", g_rccl.GetErrorString(e));
+            }
+            std::vector<rtx_ctx *> ws = workers_of(c);
+            for (size_t i = 0; i < ws.size(); ++i) ws[i]->comm = comms[i];
+        }
+        *out = c;
+        return RTX_OK;
+    });
 }
 
 void rtx_destroy(rtx_ctx *c)
 {
     if (!c) return;
-    DeviceGuard g(c->device);
-    free_scene(c);
-    if (c->d_image) (void)hipFree(c->d_image);
-    if (c->d_bytes) (void)hipFree(c->d_bytes);
-    if (c->d_wavefront) (void)hipFree(c->d_wavefront);
-    if (c->d_tiles) (void)hipFree(c->d_tiles);
-    if (c->d_stats) (void)hipFree(c->d_stats);
-    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
-    if (c->ev_stop) (void)hipEventDestroy(c->ev_stop);
-    delete c;
+    for (rtx_ctx *p : c->peers) destroy_worker(p);
+    c->peers.clear();
+    destroy_worker(c);
 }
 
 int rtx_set_scene(rtx_ctx *c, const rtx_scene *s)
@@ -459,43 +735,61 @@ int rtx_set_scene(rtx_ctx *c, const rtx_scene *s)
     if (!c) return fail(RTX_ERR_INVALID_ARG, "ctx is null");
     int rc = validate_scene(s);
     if (rc != RTX_OK) return rc;
-    DeviceGuard g(c->device);
-    if (!g.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", c->device);
-    c->have_scene = false;
-    c->scene = *s;
-    c->prims.assign(s->prims, s->prims + s->n_prims);
-    c->scene.prims = nullptr;
-    derive_lights(c->prims, c->lights);
-    switch (c->opts.accel) {
-    case RTX_ACCEL_AUTO: {
-        // planes are tested for every ray either way; with more than RTX_AUTO_BRUTE_MAX other
-        // objects the traversal is faster than the scan (measured cross-over: 6 to 10)
-        uint32_t bounded = 0;
-        for (const rtx_prim &p : c->prims) bounded += p.kind != RTX_PLANE ? 1u : 0u;
-        c->src = (bounded <= RTX_AUTO_BRUTE_MAX && s->n_prims <= RTX_MAX_LDS_PRIMS) ? rtx::kSrcLds : rtx::kSrcBvh;
-        break;
-    }
-    case RTX_ACCEL_BRUTE_LDS:
-        if (s->n_prims > RTX_MAX_LDS_PRIMS)
-            return fail(RTX_ERR_UNSUPPORTED, "%u objects exceed the LDS table limit of %u", s->n_prims,
-                        RTX_MAX_LDS_PRIMS);
-        c->src = rtx::kSrcLds;
-        break;
-    case RTX_ACCEL_BRUTE_SCALAR: c->src = rtx::kSrcScalar; break;
-    default: c->src = rtx::kSrcBvh; break;
-    }
-    rc = upload_scene(c);
-    if (rc != RTX_OK) return rc;
-    c->have_scene = true;
-    return RTX_OK;
+    return guarded("rtx_set_scene", [&]() -> int {
+        std::vector<rtx_ctx *> ws = workers_of(c);
+        for (rtx_ctx *w : ws) w->have_scene = false;
+        c->scene = *s;
+        c->prims.assign(s->prims, s->prims + s->n_prims);
+        c->scene.prims = nullptr;
+        derive_lights(c->prims, c->lights);
+        switch (c->opts.accel) {
+        case RTX_ACCEL_AUTO: {
+            // planes are tested for every ray either way; with more than RTX_AUTO_BRUTE_MAX other
+            // objects the traversal is faster than the scan (measured cross-over: 6 to 10)
+            uint32_t bounded = 0;
+            for (const rtx_prim &p : c->prims) bounded += p.kind != RTX_PLANE ? 1u : 0u;
+            c->src = (bounded <= RTX_AUTO_BRUTE_MAX && s->n_prims <= RTX_MAX_LDS_PRIMS) ? rtx::kSrcLds : rtx::kSrcBvh;
+            break;
+        }
+        case RTX_ACCEL_BRUTE_LDS:
+            if (s->n_prims > RTX_MAX_LDS_PRIMS)
+                return fail(RTX_ERR_UNSUPPORTED, "%u objects exceed the LDS table limit of %u", s->n_prims,
+                            RTX_MAX_LDS_PRIMS);
+            c->src = rtx::kSrcLds;
+            break;
+        case RTX_ACCEL_BRUTE_SCALAR: c->src = rtx::kSrcScalar; break;
+        default: c->src = rtx::kSrcBvh; break;
+        }
+        SceneBlock blk;
+        build_scene_block(c, blk);
+        for (rtx_ctx *w : ws) {
+            DeviceGuard g(w->device);
+            if (!g.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", w->device);
+            if (w != c) {
+                // what the launch and statistics code reads from a worker's host copy
+                w->scene = c->scene;
+                w->src = c->src;
+                w->prims = c->prims;
+                w->lights = c->lights;
+            }
+            rc = upload_scene_block(w, blk);
+            if (rc != RTX_OK) return rc;
+        }
+        for (rtx_ctx *w : ws) w->have_scene = true;
+        return RTX_OK;
+    });
 }
+
+}  // extern "C"
+
+namespace {
 
 // cost-ordered dispatch of the megakernel's tiles: used from this many samples and tiles on
 // (fewer tiles than two per wave slot of the GPU leave nothing to reorder)
 constexpr uint32_t kProbeSamples = 8u, kOrderedMinSamples = 64u, kOrderedMinTiles = 8192u;
 
-static int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream,
-                        bool accumulate)
+int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream,
+                 bool accumulate)
 {
     if (!c || !d_sum) return fail(RTX_ERR_INVALID_ARG, "render: null argument");
     if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_set_scene has not been called");
@@ -512,6 +806,23 @@ static int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count
     const bool stats = c->opts.collect_stats != 0;
     P.stats = stats ? c->d_stats : nullptr;
     c->stats_valid = false;
+    const uint32_t n_tiles = ((P.width + 7u) / 8u) * ((P.height + 7u) / 8u);
+    if (P.ray_depth == 0u) {
+        // src/trace.rs:12-14: the camera ray itself is cut, nothing is intersected
+        HIP_TRY(hipEventRecord(c->ev_start, stream));
+        const uint64_t n = (uint64_t)P.width * P.height * 3u;
+        hipLaunchKernelGGL(k_add_zero_samples, dim3((uint32_t)std::min<uint64_t>((n + 255u) / 256u, 4096u)), dim3(256), 0,
+                           stream, d_sum, n, accumulate ? 1 : 0, sample_count > 0u ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(c->ev_stop, stream));
+        c->timed = true;
+        if (stats) {
+            std::memset(&c->stats, 0, sizeof(c->stats));
+            c->stats.samples = (uint64_t)P.width * P.height * sample_count;
+            c->stats_valid = true;
+        }
+        return RTX_OK;
+    }
     if (stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, rtx::C_COUNT * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(c->ev_start, stream));
     if (c->opts.mode == RTX_MODE_WAVEFRONT) {
@@ -535,8 +846,8 @@ static int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count
         // of kProbeSamples samples records what each tile costs, the rest of the samples are
         // continued on top of its sums with the tiles dispatched longest first.  The split
         // changes no bits (the sums continue in sample order, as rtx_accumulate_samples does).
-        const uint32_t n_tiles = ((P.width + 7u) / 8u) * ((P.height + 7u) / 8u);
         uint32_t probe = 0;
+        uint32_t *tiles = nullptr;
         if (!stats && sample_count >= kOrderedMinSamples && n_tiles >= kOrderedMinTiles) {
             probe = kProbeSamples;
             if (c->d_tiles_words < 2u * (size_t)n_tiles) {
@@ -546,21 +857,23 @@ static int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count
                 HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_tiles), 2u * (size_t)n_tiles * sizeof(uint32_t)));
                 c->d_tiles_words = 2u * (size_t)n_tiles;
             }
+            tiles = c->d_tiles;
         }
         if (probe) {
-            uint32_t *cost = c->d_tiles, *order = c->d_tiles + n_tiles;
+            uint32_t *cost = tiles, *order = tiles + n_tiles;
+            // the tables keep the last call's contents: costs are maxima and must start from zero
             HIP_TRY(hipMemsetAsync(cost, 0, n_tiles * sizeof(uint32_t), stream));
             rtx::RenderParams A = P;
             A.sample_count = probe;
             A.tile_cost = cost;
-            HIP_TRY(rtx::launch_megakernel(A, c->src, false, stream));
+            HIP_TRY(rtx::launch_megakernel(A, c->src, false, c->pool_limit, stream));
             HIP_TRY(rtx::launch_tile_order(cost, order, n_tiles, stream));
             P.sample_first = sample_first + probe;
             P.sample_count = sample_count - probe;
             P.accumulate = 1u;
             P.tile_order = order;
         }
-        HIP_TRY(rtx::launch_megakernel(P, c->src, stats, stream));
+        HIP_TRY(rtx::launch_megakernel(P, c->src, stats, c->pool_limit, stream));
     }
     HIP_TRY(hipEventRecord(c->ev_stop, stream));
     c->timed = true;
@@ -573,6 +886,132 @@ static int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count
     }
     return RTX_OK;
 }
+
+// ---- a multi-GPU context: the sample loop cut over the workers, sums added on the devices ----
+
+// Worker g renders its share of samples [first, first + count) onto (accumulate) or into its own
+// d_image, on its own stream; ev_done marks the end of its share.  Returns without waiting.
+int render_shares(rtx_ctx *c, uint32_t first, uint32_t count, bool accumulate)
+{
+    std::vector<rtx_ctx *> ws = workers_of(c);
+    const uint32_t G = (uint32_t)ws.size();
+    const size_t floats = (size_t)c->scene.width * c->scene.height * 3u;
+    for (uint32_t g = 0; g < G; ++g) {
+        rtx_ctx *w = ws[g];
+        DeviceGuard dg(w->device);
+        if (!dg.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", w->device);
+        int rc = ensure_image(w, floats);
+        if (rc != RTX_OK) return rc;
+        uint64_t f, n;
+        split_range(count, G, g, f, n);
+        rc = render_range(w, first + (uint32_t)f, (uint32_t)n, w->d_image, w->stream, accumulate);
+        if (rc != RTX_OK) return rc;
+        HIP_TRY(hipEventRecord(w->ev_done, w->stream));
+    }
+    return RTX_OK;
+}
+
+// Adds the workers' d_image buffers and delivers the result to host memory: the mean (divide) or
+// the plain sum as floats, and / or the tone-mapped bytes of sum / divisor.  The workers' own sums
+// stay as they are, so a progressive render can go on.
+int reduce_to_host(rtx_ctx *c, float divisor, bool divide, float *host_floats, uint8_t *host_bytes)
+{
+    std::vector<rtx_ctx *> ws = workers_of(c);
+    const uint32_t G = (uint32_t)ws.size();
+    const uint64_t floats = (uint64_t)c->scene.width * c->scene.height * 3u;
+    if (c->opts.reduce == RTX_REDUCE_RCCL) {
+        for (rtx_ctx *w : ws) {
+            DeviceGuard dg(w->device);
+            int rc = ensure_reduced(w, floats);
+            if (rc != RTX_OK) return rc;
+        }
+        // one communicator rank per GPU, all driven by this thread: the calls form one group
+        RCCL_TRY(g_rccl.GroupStart());
+        for (rtx_ctx *w : ws) {
+            DeviceGuard dg(w->device);
+            int e = g_rccl.AllReduce(w->d_image, w->d_reduced, floats, kNcclFloat32, kNcclSum, w->comm, w->stream);
+            if (e != 0) {
+                (void)g_rccl.GroupEnd();
+                return fail(RTX_ERR_DEVICE, "ncclAllReduce: %s", g_rccl.GetErrorString(e));
+            }
+        }
+        RCCL_TRY(g_rccl.GroupEnd());
+        // every GPU now holds the sum; GPU 0 finishes it and sends it to the host
+        DeviceGuard dg(c->device);
+        if (host_bytes) {
+            int rc = ensure_bytes(c, floats);
+            if (rc != RTX_OK) return rc;
+            HIP_TRY(rtx::launch_tonemap(c->d_reduced, floats, divisor, c->d_bytes, c->stream));
+            HIP_TRY(hipMemcpyAsync(host_bytes, c->d_bytes, floats, hipMemcpyDeviceToHost, c->stream));
+        }
+        if (host_floats) {
+            if (divide) HIP_TRY(rtx::launch_divide(c->d_reduced, floats, divisor, c->stream));
+            HIP_TRY(hipMemcpyAsync(host_floats, c->d_reduced, floats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        }
+        for (rtx_ctx *w : ws) {
+            DeviceGuard wg(w->device);
+            HIP_TRY(hipStreamSynchronize(w->stream));
+        }
+        return RTX_OK;
+    }
+    ReduceSources S;
+    std::memset(&S, 0, sizeof(S));
+    S.n = (int)G;
+    for (uint32_t g = 0; g < G; ++g) S.src[g] = ws[g]->d_image;
+    for (uint32_t g = 0; g < G; ++g) {
+        rtx_ctx *w = ws[g];
+        uint64_t first, len;
+        image_slice(floats, G, g, first, len);
+        if (len == 0) continue;
+        DeviceGuard dg(w->device);
+        if (!dg.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", w->device);
+        int rc = ensure_reduced(w, len);
+        if (rc != RTX_OK) return rc;
+        // the slice is complete once every worker's share is
+        for (rtx_ctx *o : ws)
+            if (o != w) HIP_TRY(hipStreamWaitEvent(w->stream, o->ev_done, 0));
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>((len / 4u + 255u) / 256u + 1u, 2048u);
+        const bool div_now = divide && !host_bytes;
+        hipLaunchKernelGGL(k_reduce_slices, dim3(blocks), dim3(256), 0, w->stream, S, first, len, divisor, div_now ? 1 : 0,
+                           w->d_reduced);
+        HIP_TRY(hipGetLastError());
+        if (host_bytes) {
+            rc = ensure_bytes(w, len);
+            if (rc != RTX_OK) return rc;
+            HIP_TRY(rtx::launch_tonemap(w->d_reduced, len, divisor, w->d_bytes, w->stream));
+            HIP_TRY(hipMemcpyAsync(host_bytes + first, w->d_bytes, len, hipMemcpyDeviceToHost, w->stream));
+            if (host_floats && divide) HIP_TRY(rtx::launch_divide(w->d_reduced, len, divisor, w->stream));
+        }
+        if (host_floats)
+            HIP_TRY(hipMemcpyAsync(host_floats + first, w->d_reduced, len * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    }
+    for (rtx_ctx *w : ws) {
+        DeviceGuard dg(w->device);
+        HIP_TRY(hipStreamSynchronize(w->stream));
+    }
+    return RTX_OK;
+}
+
+bool is_multi(const rtx_ctx *c) { return c->stream != nullptr; }
+
+// what a multi-GPU render leaves for rtx_get_stats: the workers' counters added up
+void gather_stats(rtx_ctx *c)
+{
+    if (!c->opts.collect_stats) return;
+    rtx_stats total;
+    std::memset(&total, 0, sizeof(total));
+    bool valid = true;
+    for (rtx_ctx *w : workers_of(c)) {
+        valid = valid && w->stats_valid;
+        if (w->stats_valid) add_stats(total, w->stats);
+    }
+    c->stats = total;
+    c->stats_valid = valid;
+}
+
+}  // namespace
+
+extern "C" {
 
 int rtx_render_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream)
 {
@@ -608,22 +1047,31 @@ int rtx_render(rtx_ctx *c, const rtx_scene *s, float *rgb)
     if (!c || !rgb) return fail(RTX_ERR_INVALID_ARG, "rtx_render: null argument");
     int rc = rtx_set_scene(c, s);
     if (rc != RTX_OK) return rc;
-    DeviceGuard g(c->device);
-    const size_t floats = (size_t)s->width * s->height * 3u;
-    rc = ensure_image(c, floats);
-    if (rc != RTX_OK) return rc;
-    c->progress_active = false;
-    if (s->n_samples == 0) {
-        // src/main.rs:14: zero iterations leave the zero-initialised image (src/image.rs:17)
-        std::memset(rgb, 0, floats * sizeof(float));
+    return guarded("rtx_render", [&]() -> int {
+        DeviceGuard g(c->device);
+        const size_t floats = (size_t)s->width * s->height * 3u;
+        c->progress_active = false;
+        if (s->n_samples == 0) {
+            // src/main.rs:14: zero iterations leave the zero-initialised image (src/image.rs:17)
+            std::memset(rgb, 0, floats * sizeof(float));
+            return RTX_OK;
+        }
+        if (is_multi(c)) {
+            // one call from the host does everything (src/main.rs:38): split, render, add, divide
+            rc = render_shares(c, 0, s->n_samples, false);
+            if (rc == RTX_OK) rc = reduce_to_host(c, (float)s->n_samples, true, rgb, nullptr);
+            gather_stats(c);
+            return rc;
+        }
+        rc = ensure_image(c, floats);
+        if (rc != RTX_OK) return rc;
+        rc = rtx_render_samples(c, 0, s->n_samples, c->d_image, nullptr);
+        if (rc != RTX_OK) return rc;
+        rc = rtx_divide(c, c->d_image, floats, (float)s->n_samples, nullptr);
+        if (rc != RTX_OK) return rc;
+        HIP_TRY(hipMemcpy(rgb, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
         return RTX_OK;
-    }
-    rc = rtx_render_samples(c, 0, s->n_samples, c->d_image, nullptr);
-    if (rc != RTX_OK) return rc;
-    rc = rtx_divide(c, c->d_image, floats, (float)s->n_samples, nullptr);
-    if (rc != RTX_OK) return rc;
-    HIP_TRY(hipMemcpy(rgb, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
-    return RTX_OK;
+    });
 }
 
 int rtx_render_bytes(rtx_ctx *c, const rtx_scene *s, uint8_t *bytes)
@@ -631,20 +1079,28 @@ int rtx_render_bytes(rtx_ctx *c, const rtx_scene *s, uint8_t *bytes)
     if (!c || !bytes) return fail(RTX_ERR_INVALID_ARG, "rtx_render_bytes: null argument");
     int rc = rtx_set_scene(c, s);
     if (rc != RTX_OK) return rc;
-    DeviceGuard g(c->device);
-    const size_t floats = (size_t)s->width * s->height * 3u;
-    rc = ensure_image(c, floats);
-    if (rc == RTX_OK) rc = ensure_bytes(c, floats);
-    if (rc != RTX_OK) return rc;
-    c->progress_active = false;
-    // zero samples leave the zero image (src/main.rs:14, src/image.rs:17); 0 / 1 keeps it
-    rc = rtx_render_samples(c, 0, s->n_samples, c->d_image, nullptr);
-    if (rc != RTX_OK) return rc;
-    const float divisor = s->n_samples == 0 ? 1.0f : (float)s->n_samples;
-    rc = rtx_tonemap_bytes(c, c->d_image, floats, divisor, c->d_bytes, nullptr);
-    if (rc != RTX_OK) return rc;
-    HIP_TRY(hipMemcpy(bytes, c->d_bytes, floats, hipMemcpyDeviceToHost));
-    return RTX_OK;
+    return guarded("rtx_render_bytes", [&]() -> int {
+        DeviceGuard g(c->device);
+        const size_t floats = (size_t)s->width * s->height * 3u;
+        c->progress_active = false;
+        // zero samples leave the zero image (src/main.rs:14, src/image.rs:17); 0 / 1 keeps it
+        const float divisor = s->n_samples == 0 ? 1.0f : (float)s->n_samples;
+        if (is_multi(c)) {
+            rc = render_shares(c, 0, s->n_samples, false);
+            if (rc == RTX_OK) rc = reduce_to_host(c, divisor, true, nullptr, bytes);
+            gather_stats(c);
+            return rc;
+        }
+        rc = ensure_image(c, floats);
+        if (rc == RTX_OK) rc = ensure_bytes(c, floats);
+        if (rc != RTX_OK) return rc;
+        rc = rtx_render_samples(c, 0, s->n_samples, c->d_image, nullptr);
+        if (rc != RTX_OK) return rc;
+        rc = rtx_tonemap_bytes(c, c->d_image, floats, divisor, c->d_bytes, nullptr);
+        if (rc != RTX_OK) return rc;
+        HIP_TRY(hipMemcpy(bytes, c->d_bytes, floats, hipMemcpyDeviceToHost));
+        return RTX_OK;
+    });
 }
 
 int rtx_progress_begin(rtx_ctx *c, const rtx_scene *s, const float *sum, uint32_t samples_done)
@@ -655,15 +1111,21 @@ int rtx_progress_begin(rtx_ctx *c, const rtx_scene *s, const float *sum, uint32_
         return fail(RTX_ERR_INVALID_ARG, "rtx_progress_begin: %u samples done but no sum to resume from", samples_done);
     int rc = rtx_set_scene(c, s);
     if (rc != RTX_OK) return rc;
-    DeviceGuard g(c->device);
-    const size_t floats = (size_t)s->width * s->height * 3u;
-    rc = ensure_image(c, floats);
-    if (rc != RTX_OK) return rc;
-    if (sum) HIP_TRY(hipMemcpy(c->d_image, sum, floats * sizeof(float), hipMemcpyHostToDevice));
-    else HIP_TRY(hipMemset(c->d_image, 0, floats * sizeof(float)));
-    c->progress_done = samples_done;
-    c->progress_active = true;
-    return RTX_OK;
+    return guarded("rtx_progress_begin", [&]() -> int {
+        const size_t floats = (size_t)s->width * s->height * 3u;
+        // a saved sum continues on the first GPU; the others start their shares from zero
+        for (rtx_ctx *w : workers_of(c)) {
+            DeviceGuard g(w->device);
+            rc = ensure_image(w, floats);
+            if (rc != RTX_OK) return rc;
+            if (sum && w == c) HIP_TRY(hipMemcpy(w->d_image, sum, floats * sizeof(float), hipMemcpyHostToDevice));
+            else HIP_TRY(hipMemset(w->d_image, 0, floats * sizeof(float)));
+            HIP_TRY(hipDeviceSynchronize());
+        }
+        c->progress_done = samples_done;
+        c->progress_active = true;
+        return RTX_OK;
+    });
 }
 
 int rtx_progress_step(rtx_ctx *c, uint32_t sample_count)
@@ -672,37 +1134,60 @@ int rtx_progress_step(rtx_ctx *c, uint32_t sample_count)
     if (!c->progress_active) return fail(RTX_ERR_NO_SCENE, "rtx_progress_begin has not been called");
     if ((uint64_t)c->progress_done + sample_count > 0xffffffffull)
         return fail(RTX_ERR_INVALID_ARG, "sample range overflows 32 bits");
-    DeviceGuard g(c->device);
-    int rc = rtx_accumulate_samples(c, c->progress_done, sample_count, c->d_image, nullptr);
-    if (rc != RTX_OK) { c->progress_active = false; return rc; }
-    HIP_TRY(hipStreamSynchronize(nullptr));
-    c->progress_done += sample_count;
-    return RTX_OK;
+    return guarded("rtx_progress_step", [&]() -> int {
+        int rc;
+        if (is_multi(c)) {
+            rc = render_shares(c, c->progress_done, sample_count, true);
+            if (rc == RTX_OK) {
+                for (rtx_ctx *w : workers_of(c)) {
+                    DeviceGuard g(w->device);
+                    HIP_TRY(hipStreamSynchronize(w->stream));
+                }
+            }
+            gather_stats(c);
+        } else {
+            DeviceGuard g(c->device);
+            rc = rtx_accumulate_samples(c, c->progress_done, sample_count, c->d_image, nullptr);
+            if (rc == RTX_OK) HIP_TRY(hipStreamSynchronize(nullptr));
+        }
+        if (rc != RTX_OK) { c->progress_active = false; return rc; }
+        c->progress_done += sample_count;
+        return RTX_OK;
+    });
 }
 
 int rtx_progress_read(rtx_ctx *c, float *rgb_mean, float *sum, uint8_t *bytes, uint32_t *samples_done)
 {
     if (!c) return fail(RTX_ERR_INVALID_ARG, "ctx is null");
     if (!c->progress_active) return fail(RTX_ERR_NO_SCENE, "rtx_progress_begin has not been called");
-    DeviceGuard g(c->device);
-    const size_t floats = (size_t)c->scene.width * c->scene.height * 3u;
-    if (samples_done) *samples_done = c->progress_done;
-    if (sum) HIP_TRY(hipMemcpy(sum, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
-    // the mean of zero samples is the zero image the reference starts from (src/image.rs:17)
-    const float divisor = c->progress_done == 0 ? 1.0f : (float)c->progress_done;
-    if (bytes) {
-        int rc = ensure_bytes(c, floats);
-        if (rc != RTX_OK) return rc;
-        rc = rtx_tonemap_bytes(c, c->d_image, floats, divisor, c->d_bytes, nullptr);
-        if (rc != RTX_OK) return rc;
-        HIP_TRY(hipMemcpy(bytes, c->d_bytes, floats, hipMemcpyDeviceToHost));
-    }
-    if (rgb_mean) {
-        // the sum stays on the device untouched: divide on the host copy, the same IEEE division
-        HIP_TRY(hipMemcpy(rgb_mean, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < floats; ++i) rgb_mean[i] = rgb_mean[i] / divisor;
-    }
-    return RTX_OK;
+    return guarded("rtx_progress_read", [&]() -> int {
+        DeviceGuard g(c->device);
+        const size_t floats = (size_t)c->scene.width * c->scene.height * 3u;
+        if (samples_done) *samples_done = c->progress_done;
+        // the mean of zero samples is the zero image the reference starts from (src/image.rs:17)
+        const float divisor = c->progress_done == 0 ? 1.0f : (float)c->progress_done;
+        if (is_multi(c)) {
+            // the state to save is the added-up sum: a resume puts it on the first GPU
+            int rc = RTX_OK;
+            if (sum) rc = reduce_to_host(c, 1.0f, false, sum, nullptr);
+            if (rc == RTX_OK && (rgb_mean || bytes)) rc = reduce_to_host(c, divisor, true, rgb_mean, bytes);
+            return rc;
+        }
+        if (sum) HIP_TRY(hipMemcpy(sum, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
+        if (bytes) {
+            int rc = ensure_bytes(c, floats);
+            if (rc != RTX_OK) return rc;
+            rc = rtx_tonemap_bytes(c, c->d_image, floats, divisor, c->d_bytes, nullptr);
+            if (rc != RTX_OK) return rc;
+            HIP_TRY(hipMemcpy(bytes, c->d_bytes, floats, hipMemcpyDeviceToHost));
+        }
+        if (rgb_mean) {
+            // the sum stays on the device untouched: divide on the host copy, the same IEEE division
+            HIP_TRY(hipMemcpy(rgb_mean, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < floats; ++i) rgb_mean[i] = rgb_mean[i] / divisor;
+        }
+        return RTX_OK;
+    });
 }
 
 int rtx_primary(rtx_ctx *c, const rtx_scene *s, int32_t *hit_id, float *t, float *normal, uint8_t *inside)
@@ -712,11 +1197,16 @@ int rtx_primary(rtx_ctx *c, const rtx_scene *s, int32_t *hit_id, float *t, float
     if (rc != RTX_OK) return rc;
     DeviceGuard g(c->device);
     const size_t n = (size_t)s->width * s->height;
-    // one device block: ids | t | normal | inside
+    // one device block, kept by the context: ids | t | normal | inside
     const size_t bytes = n * 4 + n * 4 + n * 12 + align16(n);
-    void *d = nullptr;
-    HIP_TRY(hipMalloc(&d, bytes));
-    unsigned char *b = static_cast<unsigned char *>(d);
+    if (c->d_primary_bytes < bytes) {
+        if (c->d_primary) (void)hipFree(c->d_primary);
+        c->d_primary = nullptr;
+        c->d_primary_bytes = 0;
+        HIP_TRY(hipMalloc(&c->d_primary, bytes));
+        c->d_primary_bytes = bytes;
+    }
+    unsigned char *b = static_cast<unsigned char *>(c->d_primary);
     rtx::PrimaryParams out;
     out.hit_id = reinterpret_cast<int32_t *>(b);
     out.t = reinterpret_cast<float *>(b + n * 4);
@@ -728,7 +1218,6 @@ int rtx_primary(rtx_ctx *c, const rtx_scene *s, int32_t *hit_id, float *t, float
     if (e == hipSuccess && normal) e = hipMemcpy(normal, out.normal, n * 12, hipMemcpyDeviceToHost);
     if (e == hipSuccess && inside) e = hipMemcpy(inside, out.inside, n, hipMemcpyDeviceToHost);
     if (e == hipSuccess) e = hipDeviceSynchronize();
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(RTX_ERR_DEVICE, "primary pass: %s", hipGetErrorString(e));
     return RTX_OK;
 }
@@ -745,9 +1234,17 @@ int rtx_last_kernel_ms(rtx_ctx *c, float *ms)
 {
     if (!c || !ms) return fail(RTX_ERR_INVALID_ARG, "rtx_last_kernel_ms: null argument");
     if (!c->timed) return fail(RTX_ERR_NO_SCENE, "nothing has been rendered yet");
-    DeviceGuard g(c->device);
-    HIP_TRY(hipEventSynchronize(c->ev_stop));
-    HIP_TRY(hipEventElapsedTime(ms, c->ev_start, c->ev_stop));
+    // a multi-GPU context: its GPUs run side by side, the render takes as long as the slowest
+    float worst = 0.0f;
+    for (rtx_ctx *w : workers_of(c)) {
+        if (!w->timed) continue;
+        DeviceGuard g(w->device);
+        float one = 0.0f;
+        HIP_TRY(hipEventSynchronize(w->ev_stop));
+        HIP_TRY(hipEventElapsedTime(&one, w->ev_start, w->ev_stop));
+        worst = std::max(worst, one);
+    }
+    *ms = worst;
     return RTX_OK;
 }
 
@@ -758,6 +1255,12 @@ int rtx_get_lights(rtx_ctx *c, int32_t *indices, int32_t capacity)
     int32_t n = (int32_t)c->lights.size();
     for (int32_t i = 0; i < n && i < capacity && indices; ++i) indices[i] = c->lights[i];
     return n;
+}
+
+int rtx_device_count(rtx_ctx *c)
+{
+    if (!c) return fail(RTX_ERR_INVALID_ARG, "ctx is null");
+    return (int)(1 + c->peers.size());
 }
 
 }  // extern "C"

@@ -83,7 +83,8 @@ struct PrimaryParams {
 enum : int { kSrcLds = 0, kSrcScalar = 1, kSrcBvh = 2 };
 // scenes with more than kFewLights lights run the kernels built with the candidate-mask light pdf
 constexpr uint32_t kFewLights = 2;
-hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, hipStream_t stream);
+// pool_limit caps the hand-over pool of a wave (entries; kPoolEntriesMax = whatever fits the LDS)
+hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, uint32_t pool_limit, hipStream_t stream);
 // order[0..n_tiles) = the tiles by decreasing cost[] (buckets of one unit, costs above
 // kTileCostMax share the first bucket)
 constexpr uint32_t kTileCostMax = 2047u;

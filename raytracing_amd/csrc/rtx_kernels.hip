@@ -342,7 +342,7 @@ static void launch_megakernel_src(const RenderParams &p, bool stats, dim3 grid, 
     }
 }
 
-hipError_t launch_megakernel(const RenderParams &p0, int src, bool stats, hipStream_t stream)
+hipError_t launch_megakernel(const RenderParams &p0, int src, bool stats, uint32_t pool_limit, hipStream_t stream)
 {
     RenderParams p = p0;
     const dim3 grid = tile_grid(p);
@@ -351,8 +351,7 @@ hipError_t launch_megakernel(const RenderParams &p0, int src, bool stats, hipStr
     const size_t fixed = fixed_lds_bytes(p, src);
     const size_t budget = 40u * 1024u;
     p.pool_entries = fixed < budget ? (uint32_t)std::min<size_t>(kPoolEntriesMax, (budget - fixed) / (4u * sizeof(float4))) : 0u;
-    // diagnostic knob (tests, measurements): a smaller pool, 0 = no hand-over
-    if (const char *e = getenv("RTX_POOL_ENTRIES")) p.pool_entries = std::min<uint32_t>(p.pool_entries, (uint32_t)strtoul(e, nullptr, 10));
+    p.pool_entries = std::min(p.pool_entries, pool_limit);
     const size_t lds = fixed + (size_t)p.pool_entries * 4u * sizeof(float4);
     if (src == kSrcLds) launch_megakernel_src<kSrcLds>(p, stats, grid, lds, stream);
     else if (src == kSrcScalar) launch_megakernel_src<kSrcScalar>(p, stats, grid, lds, stream);

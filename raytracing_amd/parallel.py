@@ -41,5 +41,7 @@ def render_distributed(renderer, scene, buf, process_group=None):
         buf.zero_()
     if world > 1:
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
-    renderer.divide(buf.data_ptr(), buf.numel(), float(scene.n_samples), stream)
+    # zero samples leave the zero image the reference starts from (src/main.rs:14, src/image.rs:17)
+    if scene.n_samples > 0:
+        renderer.divide(buf.data_ptr(), buf.numel(), float(scene.n_samples), stream)
     return buf

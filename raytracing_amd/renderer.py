@@ -40,6 +40,7 @@ SYMBOLS = {
     "rtx_get_stats": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_stats)]),
     "rtx_last_kernel_ms": (C.c_int, [C.c_void_p, _FP]),
     "rtx_get_lights": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
+    "rtx_device_count": (C.c_int, [C.c_void_p]),
 }
 
 _lib = None
@@ -85,16 +86,22 @@ def _check(rc: int):
 
 
 class Renderer:
-    """One rtx_ctx: drives one GPU from one host thread."""
+    """One rtx_ctx: drives one GPU -- or, with `devices`, several GPUs of the node -- from one
+    host thread."""
 
     def __init__(self, seed: int = 1, mode: int = _abi.MODE_MEGAKERNEL, accel: int = _abi.ACCEL_AUTO,
                  rng_mode: int = _abi.RNG_PHILOX, const_words=(0, 0, 0, 0), device: int = -1,
-                 collect_stats: bool = False):
+                 collect_stats: bool = False, devices=None, reduce: int = _abi.REDUCE_P2P):
         self._lib = load_library()
         o = _abi.rtx_opts()
         o.seed, o.mode, o.accel, o.rng_mode = seed, mode, accel, rng_mode
         o.const_words[:] = const_words
         o.device, o.collect_stats = device, int(collect_stats)
+        o.reduce = reduce
+        if devices is not None:
+            # HIP ordinals the sample loop is split over (an ordinal may repeat)
+            self._devices = (C.c_int32 * len(devices))(*devices)
+            o.n_devices, o.devices = len(devices), self._devices
         self._ctx = C.c_void_p()
         _check(self._lib.rtx_create(C.byref(self._ctx), C.byref(o)))
         self._scene: Optional[Scene] = None
@@ -121,6 +128,9 @@ class Renderer:
         s, keep = scene.to_ctypes()
         _check(self._lib.rtx_set_scene(self._ctx, C.byref(s)))
         self._scene = scene
+
+    def device_count(self) -> int:
+        return _check(self._lib.rtx_device_count(self._ctx))
 
     def lights(self):
         n = _check(self._lib.rtx_get_lights(self._ctx, None, 0))

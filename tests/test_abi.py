@@ -35,7 +35,8 @@ def test_struct_layouts():
     assert _abi.rtx_prim.material.offset == 68 and _abi.rtx_prim.ior.offset == 72
     assert C.sizeof(_abi.rtx_scene) == 96 and _abi.rtx_scene.prims.offset == 88
     assert _abi.rtx_scene.cam_axis.offset == 40 and _abi.rtx_scene.tg_fov_x.offset == 76
-    assert C.sizeof(_abi.rtx_opts) == 48 and _abi.rtx_opts.const_words.offset == 20
+    assert C.sizeof(_abi.rtx_opts) == 64 and _abi.rtx_opts.const_words.offset == 20
+    assert _abi.rtx_opts.n_devices.offset == 44 and _abi.rtx_opts.devices.offset == 56
     assert C.sizeof(_abi.rtx_stats) == 23 * 8
 
 

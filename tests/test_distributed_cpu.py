@@ -79,12 +79,16 @@ def _worker(rank, world, port, spp, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,spp", [(2, 8), (3, 7), (2, 1)])
+@pytest.mark.parametrize("world,spp", [(2, 8), (3, 7), (2, 1), (2, 0)])
 def test_spp_split_allreduce_matches_single_rank(tmp_path, world, spp, oracle):
     out = str(tmp_path / "img.npy")
     mp.spawn(_worker, args=(world, _free_port(), spp, out), nprocs=world, join=True)
     got = np.load(out)
     sc = reference_scene(width=24, height=16, n_samples=spp)
+    if spp == 0:
+        # no sample step runs (src/main.rs:14): the zero image (src/image.rs:17), not 0 / 0
+        assert not got.any() and not oracle.render(sc, seed=5, order=oracle.ORDER_REFERENCE).any()
+        return
     want_fwd = oracle.render(sc, seed=5, order=oracle.ORDER_FORWARD).reshape(-1)
     want_ref = oracle.render(sc, seed=5, order=oracle.ORDER_REFERENCE).reshape(-1)
     # partial sums are added in a different order than a single rank adds samples

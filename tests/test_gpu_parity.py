@@ -173,6 +173,35 @@ def test_empty_scene_and_zero_samples(oracle):
         assert np.all(img0 == 0)
 
 
+@pytest.mark.parametrize("mode", [_abi.MODE_MEGAKERNEL, _abi.MODE_WAVEFRONT])
+def test_ray_depth_zero_renders_black(oracle, mode):
+    """RAY_DEPTH 0: the camera ray itself is cut before it intersects anything (src/trace.rs:12-14),
+    so neither the background nor a light shows.  Every accel, both kernels, and a continued sum."""
+    import torch
+    sc = reference_scene(width=40, height=24, n_samples=3).replace(ray_depth=0, background=(0.5, 0.25, 1.0))
+    want = oracle.render(sc, seed=1, order=oracle.ORDER_FORWARD)
+    want_ref = oracle.render(sc, seed=1, order=oracle.ORDER_REFERENCE)
+    assert not want.any() and not want_ref.any()
+    for accel in (_abi.ACCEL_BRUTE_LDS, _abi.ACCEL_BRUTE_SCALAR, _abi.ACCEL_BVH):
+        with Renderer(seed=1, mode=mode, accel=accel, collect_stats=True) as r:
+            got = r.render(sc)
+            st = r.stats()
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), accel
+        assert st["samples"] == 40 * 24 * 3 and st["rays"] == 0
+    # a continued sum keeps its values (and -0 + 0 = +0, as the additions of zero radiance give)
+    with Renderer(seed=1, mode=mode) as r:
+        r.set_scene(sc)
+        buf = torch.full((40 * 24 * 3,), 1.5, dtype=torch.float32, device="cuda")
+        buf[0] = -0.0
+        r.accumulate_samples(0, 2, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        out = buf.cpu().numpy()
+        assert out[0] == 0 and not np.signbit(out[0]) and (out[1:] == 1.5).all()
+        r.render_samples(0, 2, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert not buf.cpu().numpy().any()
+
+
 def test_error_codes():
     from raytracing_amd import Prim
     with Renderer() as r:
