@@ -169,6 +169,19 @@ int rtx_render(rtx_ctx *ctx, const rtx_scene *scene, float *rgb);
 int rtx_render_samples(rtx_ctx *ctx, uint32_t sample_first, uint32_t sample_count,
                        float *d_sum, void *hip_stream);
 
+/* rtx_render_samples for callers that cannot allocate device memory: code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
+ * reference.  Same arguments, same output bits as rtx_render_samples, but no device or pinned
+ * memory is allocated or freed on any path: the tile cost / dispatch order tables of the
+ * megakernel live in a static device array of RTX_STATIC_MAX_TILES * 8 bytes (2 MiB) that every
+ * GPU the library runs on holds until the process ends.  RTX_ERR_UNSUPPORTED for an image of more
+ * than RTX_STATIC_MAX_TILES tiles of 8 x 8 pixels (e.g. beyond 4096 x 4096) and for the wavefront
+ * variant on a BVH scene (its path state is a device block).  All contexts on one GPU share that
+ * GPU's array: calls that overlap in time on one GPU race, whatever their streams. */
+#define RTX_STATIC_MAX_TILES 262144u
+int rtx_render_samples_static(rtx_ctx *ctx, uint32_t sample_first, uint32_t sample_count,
+                              float *d_sum, void *hip_stream);
+
 /* As rtx_render_samples, but the per-pixel sums CONTINUE from the values already in
  * d_sum: calls over [0, a) and then [a, b) leave the bits one call over [0, b)
  * writes.  src/main.rs:23-27 keeps the image a valid mean after every sample step so

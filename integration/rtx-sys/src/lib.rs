@@ -35,6 +35,7 @@ pub const RTX_RNG_CONST: u32 = 1;
 pub const RTX_REDUCE_P2P: u32 = 0;
 pub const RTX_REDUCE_RCCL: u32 = 1;
 pub const RTX_MAX_DEVICES: usize = 16;
+pub const RTX_STATIC_MAX_TILES: u32 = 262144;
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
@@ -118,6 +119,7 @@ extern "C" {
     pub fn rtx_set_scene(ctx: *mut rtx_ctx, scene: *const rtx_scene) -> c_int;
     pub fn rtx_render(ctx: *mut rtx_ctx, scene: *const rtx_scene, rgb: *mut f32) -> c_int;
     pub fn rtx_render_samples(ctx: *mut rtx_ctx, sample_first: u32, sample_count: u32, d_sum: *mut f32, hip_stream: *mut c_void) -> c_int;
+    pub fn rtx_render_samples_static(ctx: *mut rtx_ctx, sample_first: u32, sample_count: u32, d_sum: *mut f32, hip_stream: *mut c_void) -> c_int;
     pub fn rtx_accumulate_samples(ctx: *mut rtx_ctx, sample_first: u32, sample_count: u32, d_sum: *mut f32, hip_stream: *mut c_void) -> c_int;
     pub fn rtx_divide(ctx: *mut rtx_ctx, d_rgb: *mut f32, n_floats: u64, divisor: f32, hip_stream: *mut c_void) -> c_int;
     pub fn rtx_tonemap_bytes(ctx: *mut rtx_ctx, d_sum: *const f32, n_floats: u64, divisor: f32, d_bytes: *mut u8, hip_stream: *mut c_void) -> c_int;

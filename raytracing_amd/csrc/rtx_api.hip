@@ -20,6 +20,12 @@
 #include <new>
 #include <vector>
 
+// Tile cost and dispatch order tables for rtx_render_samples_static, the entry point that may not
+// allocate: one copy per GPU, held until the process ends.  Host code never uses this name as an
+// address (it is a host-side stand-in): rtx_create asks the runtime for the device address, once
+// per context with the context's device current, and everything else goes through that pointer.
+static __device__ __align__(256) uint32_t scratch[2u * RTX_STATIC_MAX_TILES];
+
 namespace {
 
 // fixed storage: reporting an error must not allocate (it may be reporting an allocation failure)
@@ -192,6 +198,7 @@ struct rtx_ctx {
     size_t d_wavefront_bytes = 0;
     uint32_t *d_tiles = nullptr;  // cost and dispatch order of the 8x8 tiles, n_tiles words each
     size_t d_tiles_words = 0;
+    uint32_t *static_tiles = nullptr;   // device address of this GPU's `scratch`
     uint32_t pool_limit = rtx::kPoolEntriesMax;   // cap of the megakernel's hand-over pool (RTX_POOL_ENTRIES)
     unsigned long long *d_stats = nullptr;
     rtx_stats stats{};
@@ -609,6 +616,8 @@ int create_worker(rtx_ctx **out, const rtx_opts *opts, int dev, bool own_stream)
     if (e == hipSuccess) e = hipEventCreate(&c->ev_stop);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming);
     if (e == hipSuccess && own_stream) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    // this GPU's copy of the static tables (the device is current): the address every later use takes
+    if (e == hipSuccess) e = hipGetSymbolAddress(reinterpret_cast<void **>(&c->static_tiles), HIP_SYMBOL(scratch));
     if (e != hipSuccess) {
         rtx_destroy(c);
         return fail(RTX_ERR_DEVICE, "context set-up on device %d: %s", dev, hipGetErrorString(e));
@@ -788,8 +797,10 @@ namespace {
 // (fewer tiles than two per wave slot of the GPU leave nothing to reorder)
 constexpr uint32_t kProbeSamples = 8u, kOrderedMinSamples = 64u, kOrderedMinTiles = 8192u;
 
+// `no_alloc`: the caller may not allocate device memory -- the tile tables are this GPU's static
+// ones, and whatever would need a fresh block is refused.
 int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream,
-                 bool accumulate)
+                 bool accumulate, bool no_alloc = false)
 {
     if (!c || !d_sum) return fail(RTX_ERR_INVALID_ARG, "render: null argument");
     if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_set_scene has not been called");
@@ -823,6 +834,14 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
         }
         return RTX_OK;
     }
+    if (no_alloc) {
+        if (c->opts.mode == RTX_MODE_WAVEFRONT && !rtx::wavefront_state_in_lds(P, c->src))
+            return fail(RTX_ERR_UNSUPPORTED,
+                        "rtx_render_samples_static: the wavefront variant keeps its path state in device memory for BVH scenes");
+        if (n_tiles > RTX_STATIC_MAX_TILES)
+            return fail(RTX_ERR_UNSUPPORTED, "rtx_render_samples_static: %u x %u has %u tiles of 8 x 8 pixels, the static tables hold %u",
+                        P.width, P.height, n_tiles, (unsigned)RTX_STATIC_MAX_TILES);
+    }
     if (stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, rtx::C_COUNT * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(c->ev_start, stream));
     if (c->opts.mode == RTX_MODE_WAVEFRONT) {
@@ -850,14 +869,18 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
         uint32_t *tiles = nullptr;
         if (!stats && sample_count >= kOrderedMinSamples && n_tiles >= kOrderedMinTiles) {
             probe = kProbeSamples;
-            if (c->d_tiles_words < 2u * (size_t)n_tiles) {
-                if (c->d_tiles) (void)hipFree(c->d_tiles);
-                c->d_tiles = nullptr;
-                c->d_tiles_words = 0;
-                HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_tiles), 2u * (size_t)n_tiles * sizeof(uint32_t)));
-                c->d_tiles_words = 2u * (size_t)n_tiles;
+            if (no_alloc) {
+                tiles = c->static_tiles;
+            } else {
+                if (c->d_tiles_words < 2u * (size_t)n_tiles) {
+                    if (c->d_tiles) (void)hipFree(c->d_tiles);
+                    c->d_tiles = nullptr;
+                    c->d_tiles_words = 0;
+                    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_tiles), 2u * (size_t)n_tiles * sizeof(uint32_t)));
+                    c->d_tiles_words = 2u * (size_t)n_tiles;
+                }
+                tiles = c->d_tiles;
             }
-            tiles = c->d_tiles;
         }
         if (probe) {
             uint32_t *cost = tiles, *order = tiles + n_tiles;
@@ -1021,6 +1044,11 @@ int rtx_render_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count,
 int rtx_accumulate_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream)
 {
     return render_range(c, sample_first, sample_count, d_sum, hip_stream, true);
+}
+
+int rtx_render_samples_static(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream)
+{
+    return render_range(c, sample_first, sample_count, d_sum, hip_stream, false, true);
 }
 
 int rtx_tonemap_bytes(rtx_ctx *c, const float *d_sum, uint64_t n_floats, float divisor, uint8_t *d_bytes,

@@ -28,6 +28,7 @@ SYMBOLS = {
     "rtx_set_scene": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene)]),
     "rtx_render": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene), _FP]),
     "rtx_render_samples": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "rtx_render_samples_static": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rtx_accumulate_samples": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rtx_tonemap_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p]),
     "rtx_render_bytes": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene), C.POINTER(C.c_uint8)]),
@@ -152,6 +153,11 @@ class Renderer:
         """Sum of samples [first, first+count) into a device buffer (raw pointer)."""
         _check(self._lib.rtx_render_samples(self._ctx, sample_first, sample_count,
                                             C.c_void_p(d_sum_ptr), C.c_void_p(stream)))
+
+    def render_samples_static(self, sample_first: int, sample_count: int, d_sum_ptr: int, stream: int = 0):
+        """render_samples without any device allocation (static tile tables)."""
+        _check(self._lib.rtx_render_samples_static(self._ctx, sample_first, sample_count,
+                                                   C.c_void_p(d_sum_ptr), C.c_void_p(stream)))
 
     def accumulate_samples(self, sample_first: int, sample_count: int, d_sum_ptr: int, stream: int = 0):
         """As render_samples, continuing the sums already in the device buffer."""
