@@ -68,6 +68,80 @@ RTX_DEV bool slab_test(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint3
 // a ray whose margin reaches this many grid units takes every node
 constexpr float kBvhMaxMargin = 16384.0f;
 
+// A ray prepared for the node tests: its reciprocal direction and the two slab offsets on the node
+// grid (see slab_test), and whether its margin is so large that it takes every node.
+struct BvhRay {
+    V3 inv, oi_lo, oi_hi;
+    bool far;
+};
+// The ray on the node grid, and its margin.  The node boxes bound the zone in which the
+// object tests can report a hit for origins inside the grid; the zone grows by at most
+// far_slope per world unit the origin lies outside it (rtx_bvh.cpp: world_bounds), and the
+// f32 value of the origin in grid units is off by up to 2^-23 of its magnitude.
+RTX_DEV BvhRay bvh_ray_setup(const BvhView &B, V3 o, V3 d)
+{
+    BvhRay R;
+    const V3 gs = v3(B.grid_inv_step[0], B.grid_inv_step[1], B.grid_inv_step[2]);
+    const V3 og = cmul(o - v3(B.grid_base[0], B.grid_base[1], B.grid_base[2]), gs);
+    const V3 dg = cmul(d, gs);
+    R.inv = cdiv(v3(1.0f, 1.0f, 1.0f), dg);
+    const float gmax = (float)kBvhGridMax;
+    const V3 outside = v3(fmaxf(fmaxf(-og.x, og.x - gmax), 0.0f), fmaxf(fmaxf(-og.y, og.y - gmax), 0.0f),
+                          fmaxf(fmaxf(-og.z, og.z - gmax), 0.0f));                      // grid units
+    const float outside_world = (outside.x * B.grid_step[0] + outside.y * B.grid_step[1]) + outside.z * B.grid_step[2];
+    const float grow = B.far_slope * outside_world * 1.01f;                             // world units
+    const V3 margin = v3(grow * gs.x + 4e-7f * (fabsf(og.x) + gmax), grow * gs.y + 4e-7f * (fabsf(og.y) + gmax),
+                         grow * gs.z + 4e-7f * (fabsf(og.z) + gmax));                   // grid units
+    R.oi_lo = cmul(og + margin, R.inv);
+    R.oi_hi = cmul(og - margin, R.inv);
+    // q * inv - oi must not overflow in either product (then it would no longer be the distance
+    // to plane q): an axis on which it could -- a direction almost parallel to the planes, on a
+    // grid stretched by a far-away object -- gets NaN offsets and never culls
+    const float kNaN = __int_as_float(0x7fc00000);
+    if (!(fabsf(R.inv.x) * (fabsf(og.x) + margin.x + gmax) < 3e38f)) R.oi_lo.x = R.oi_hi.x = kNaN;
+    if (!(fabsf(R.inv.y) * (fabsf(og.y) + margin.y + gmax) < 3e38f)) R.oi_lo.y = R.oi_hi.y = kNaN;
+    if (!(fabsf(R.inv.z) * (fabsf(og.z) + margin.z + gmax) < 3e38f)) R.oi_lo.z = R.oi_hi.z = kNaN;
+    // written so that a NaN counts as far
+    R.far = !(fmaxf(fmaxf(margin.x, margin.y), margin.z) < kBvhMaxMargin);
+    return R;
+}
+
+// One node visit: tests both children of inner node `cur` against the ray, descends into the
+// nearer one that is hit (postponing the other on the lane's stack, one column of `stack` with
+// stride BLOCK) or pops the stack.  cur >= 0 inner node, < 0 leaf of object ~cur, kBvhEmpty =
+// nothing left.
+template <bool STATS, int BLOCK>
+RTX_DEV void bvh_node_step(const BvhView &B, const BvhRay &R, float best_t, int32_t &cur, int &sp, int32_t *stack,
+                           Counters<STATS> &cnt)
+{
+    const uint4 *nd = B.nodes + 2 * (size_t)cur;
+    const uint4 a = nd[0], b = nd[1];
+    const int32_t r0 = (int32_t)b.z, r1 = (int32_t)b.w;
+    float d0 = 0.0f, d1 = 0.0f;
+    bool h0 = slab_test(a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, R.oi_lo,
+                        R.oi_hi, R.inv, best_t, d0);
+    bool h1 = slab_test(a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, R.oi_lo,
+                        R.oi_hi, R.inv, best_t, d1);
+    h0 = (h0 || R.far) && r0 != kBvhEmpty;
+    h1 = (h1 || R.far) && r1 != kBvhEmpty;
+    if constexpr (STATS) cnt.v[C_NODE_TESTS] += 2;
+    if (h0 && h1) {
+        const bool first0 = d0 <= d1;
+        stack[sp * BLOCK] = first0 ? r1 : r0;   // depth <= kBvhMaxDepth < kBvhStackSize
+        sp++;
+        cur = first0 ? r0 : r1;
+    } else if (h0) {
+        cur = r0;
+    } else if (h1) {
+        cur = r1;
+    } else if (sp > 0) {
+        sp--;
+        cur = stack[sp * BLOCK];
+    } else {
+        cur = kBvhEmpty;
+    }
+}
+
 // BLOCK = threads per workgroup of the calling kernel (the stack array is sized for it).
 // DYN_STACK: the caller provides the stacks (B.stack_entries x BLOCK words of LDS: a tree of
 // depth d never holds more than d postponed nodes) instead of the static kBvhStackSize x BLOCK.
@@ -96,63 +170,12 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
     if (B.n_nodes == 0) return best;
     const bool leaves_plain = all_plain && B.leaves_identity != 0u;   // wave-uniform
 
-    // The ray on the node grid, and its margin.  The node boxes bound the zone in which the
-    // object tests can report a hit for origins inside the grid; the zone grows by at most
-    // far_slope per world unit the origin lies outside it (rtx_bvh.cpp: world_bounds), and the
-    // f32 value of the origin in grid units is off by up to 2^-23 of its magnitude.
-    const V3 gs = v3(B.grid_inv_step[0], B.grid_inv_step[1], B.grid_inv_step[2]);
-    const V3 og = cmul(o - v3(B.grid_base[0], B.grid_base[1], B.grid_base[2]), gs);
-    const V3 dg = cmul(d, gs);
-    const V3 inv = cdiv(v3(1.0f, 1.0f, 1.0f), dg);
-    const float gmax = (float)kBvhGridMax;
-    const V3 outside = v3(fmaxf(fmaxf(-og.x, og.x - gmax), 0.0f), fmaxf(fmaxf(-og.y, og.y - gmax), 0.0f),
-                          fmaxf(fmaxf(-og.z, og.z - gmax), 0.0f));                      // grid units
-    const float outside_world = (outside.x * B.grid_step[0] + outside.y * B.grid_step[1]) + outside.z * B.grid_step[2];
-    const float grow = B.far_slope * outside_world * 1.01f;                             // world units
-    const V3 margin = v3(grow * gs.x + 4e-7f * (fabsf(og.x) + gmax), grow * gs.y + 4e-7f * (fabsf(og.y) + gmax),
-                         grow * gs.z + 4e-7f * (fabsf(og.z) + gmax));                   // grid units
-    V3 oi_lo = cmul(og + margin, inv), oi_hi = cmul(og - margin, inv);
-    // q * inv - oi must not overflow in either product (then it would no longer be the distance
-    // to plane q): an axis on which it could -- a direction almost parallel to the planes, on a
-    // grid stretched by a far-away object -- gets NaN offsets and never culls
-    const float kNaN = __int_as_float(0x7fc00000);
-    if (!(fabsf(inv.x) * (fabsf(og.x) + margin.x + gmax) < 3e38f)) oi_lo.x = oi_hi.x = kNaN;
-    if (!(fabsf(inv.y) * (fabsf(og.y) + margin.y + gmax) < 3e38f)) oi_lo.y = oi_hi.y = kNaN;
-    if (!(fabsf(inv.z) * (fabsf(og.z) + margin.z + gmax) < 3e38f)) oi_lo.z = oi_hi.z = kNaN;
-    // written so that a NaN counts as far
-    const bool far = !(fmaxf(fmaxf(margin.x, margin.y), margin.z) < kBvhMaxMargin);
+    const BvhRay R = bvh_ray_setup(B, o, d);
     int sp = 0;
     int32_t cur = 0;  // >= 0 inner node, < 0 leaf of object ~cur, kBvhEmpty = finished
     for (;;) {
         // node phase: every lane descends until it holds a leaf or has finished
-        while (cur >= 0) {
-            const uint4 *nd = B.nodes + 2 * (size_t)cur;
-            const uint4 a = nd[0], b = nd[1];
-            const int32_t r0 = (int32_t)b.z, r1 = (int32_t)b.w;
-            float d0 = 0.0f, d1 = 0.0f;
-            bool h0 = slab_test(a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, oi_lo,
-                                oi_hi, inv, best_t, d0);
-            bool h1 = slab_test(a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, oi_lo,
-                                oi_hi, inv, best_t, d1);
-            h0 = (h0 || far) && r0 != kBvhEmpty;
-            h1 = (h1 || far) && r1 != kBvhEmpty;
-            if constexpr (STATS) cnt.v[C_NODE_TESTS] += 2;
-            if (h0 && h1) {
-                const bool first0 = d0 <= d1;
-                stack[sp * BLOCK] = first0 ? r1 : r0;   // depth <= kBvhMaxDepth < kBvhStackSize
-                sp++;
-                cur = first0 ? r0 : r1;
-            } else if (h0) {
-                cur = r0;
-            } else if (h1) {
-                cur = r1;
-            } else if (sp > 0) {
-                sp--;
-                cur = stack[sp * BLOCK];
-            } else {
-                cur = kBvhEmpty;
-            }
-        }
+        while (cur >= 0) bvh_node_step<STATS, BLOCK>(B, R, best_t, cur, sp, stack, cnt);
         if (__ballot(cur != kBvhEmpty) == 0ull) break;
         // leaf phase
         if (cur < 0 && cur != kBvhEmpty) {

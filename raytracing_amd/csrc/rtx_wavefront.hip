@@ -38,16 +38,42 @@ namespace rtx {
 
 namespace {
 
-// shape of a workgroup: threads, 8x8 tiles and pixels it owns (pixel numbers fit 16-bit queue entries)
-template <bool LDS_STATE>
-struct WfShape {
-    static constexpr uint32_t kThreads = 512u;
-    static constexpr uint32_t kTiles = LDS_STATE ? 16u : 64u;
+// Shape of a workgroup: threads, 8x8 tiles and pixels it owns (pixel numbers fit 16-bit queue
+// entries), and where the path records live.  Three shapes are in use:
+//   ShapeScan     512 threads, 16 tiles, records in LDS: the linear scan, two workgroups per CU;
+//   ShapeBvhLds    64 threads,  2 tiles, records in LDS: BVH scenes with a shallow tree.  A
+//                 workgroup is ONE wave: its barriers cost nothing, and no wave ever waits for
+//                 another one's longest traversal;
+//   ShapeBvhHbm    64 threads,  4 tiles, records in device memory: deep trees, whose traversal
+//                 stacks leave no room for records in LDS.
+// Measured on 10 000 objects (ms per frame of 64 spp) with the records in device memory:
+// 512 threads x 64 tiles 418, 256 x 32 375, 256 x 16 287, 128 x 8 286, 64 x 8 379 (LDS limits
+// the waves per CU), 64 x 4 267.
+template <uint32_t THREADS, uint32_t TILES, bool LDS_STATE>
+struct WfShapeT {
+    static constexpr uint32_t kThreads = THREADS;
+    static constexpr uint32_t kTiles = TILES;
+    static constexpr bool kLdsState = LDS_STATE;
     static constexpr uint32_t kPixels = kTiles * 64u;
     static constexpr uint32_t kPlane = LDS_STATE ? kPixels : 0u;   // see wf_at
     // the start-up loop walks the pixels in steps of kThreads and must not run past them
     static_assert(kPixels % kThreads == 0 && kPixels <= 65536u, "a workgroup's pixels: a multiple of its threads, 16-bit numbers");
 };
+#ifndef RTX_WF_SCAN_THREADS
+#define RTX_WF_SCAN_THREADS 512u
+#endif
+#ifndef RTX_WF_SCAN_TILES
+#define RTX_WF_SCAN_TILES 16u
+#endif
+#ifndef RTX_WF_BVH_LDS_TILES
+#define RTX_WF_BVH_LDS_TILES 2u
+#endif
+#ifndef RTX_WF_BVH_HBM_TILES
+#define RTX_WF_BVH_HBM_TILES 4u
+#endif
+using ShapeScan = WfShapeT<RTX_WF_SCAN_THREADS, RTX_WF_SCAN_TILES, true>;
+using ShapeBvhLds = WfShapeT<64u, RTX_WF_BVH_LDS_TILES, true>;
+using ShapeBvhHbm = WfShapeT<64u, RTX_WF_BVH_HBM_TILES, false>;
 
 enum : int { Q_ACTIVE0 = 0, Q_ACTIVE1, Q_FRESH0, Q_FRESH1, Q_DIFFUSE, Q_METALLIC, Q_DIELECTRIC, Q_COUNT };
 
@@ -55,9 +81,21 @@ template <uint32_t PIXELS>
 struct WfLds {
     uint16_t queue[Q_COUNT][PIXELS];
     uint32_t count[Q_COUNT];
+    uint32_t next;   // BVH extend stage: rays of the active queue handed out so far
 };
 
 extern __shared__ float4 rtx_smem[];
+
+// Build with -DRTX_WF_DEBUG to count, per launch, the rounds of every stage and the lanes they
+// served (rtx_wf_debug_read): how full the waves run where.
+#ifdef RTX_WF_DEBUG
+__device__ unsigned long long g_wf_dbg[16];
+#define WF_DBG(i, n) dbg[i] += (n)
+#else
+#define WF_DBG(i, n) ((void)0)
+#endif
+enum { D_NODE_ROUNDS = 0, D_NODE_LANES, D_LEAF_ROUNDS, D_LEAF_LANES, D_SERVE_ROUNDS, D_SERVE_DONE, D_SERVE_FETCHED,
+       D_GEN_ROUNDS, D_GEN_LANES, D_SHADE_ROUNDS, D_SHADE_LANES, D_ITERATIONS, D_COUNT };
 
 // wave64 compaction into an LDS queue: lanes with `pred` append `value`
 template <uint32_t PIXELS>
@@ -148,12 +186,14 @@ RTX_DEV bool wf_finish_path(const RenderParams &P, float4 *rec, uint32_t local, 
 // one material's queue: scatter (src/trace.rs:25-68 for that material)
 template <int MATERIAL, bool STATS, bool MANY_LIGHTS, class SHAPE>
 RTX_DEV void wf_shade(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPixels> &L, const Table &tab, uint32_t nxt,
-                      Counters<STATS> &cnt)
+                      Counters<STATS> &cnt, uint32_t *dbg)
 {
     const uint32_t count = L.count[Q_DIFFUSE + MATERIAL];
     for (uint32_t base = 0; base < count; base += SHAPE::kThreads) {
         const uint32_t i = base + threadIdx.x;
         const bool valid = i < count;
+        WF_DBG(D_SHADE_ROUNDS, 1u);
+        WF_DBG(D_SHADE_LANES, (uint32_t)__popcll(__ballot(valid)));
         uint32_t local = 0;
         bool go_on = false, refresh = false;
         if (valid) {
@@ -176,12 +216,177 @@ RTX_DEV void wf_shade(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPixels> 
     }
 }
 
-template <int SRC, bool STATS, bool MANY_LIGHTS, bool LDS_STATE>
-__global__ void __launch_bounds__(WfShape<LDS_STATE>::kThreads) k_wavefront(const RenderParams P, const WfState S)
+// Rough costs, in instructions, of the three things a wave of the BVH extend stage can do next;
+// only their ratios matter (they weigh how many lanes each would serve).
+#ifndef RTX_WF_COST_NODE
+#define RTX_WF_COST_NODE 1u      // a batch of node steps
+#endif
+#ifndef RTX_WF_COST_LEAF
+#define RTX_WF_COST_LEAF 3u      // one object test
+#endif
+#ifndef RTX_WF_COST_SERVE
+#define RTX_WF_COST_SERVE 6u     // write back finished rays, fetch new ones, test the plane list
+#endif
+#ifndef RTX_WF_NODE_BATCH
+#define RTX_WF_NODE_BATCH 2
+#endif
+// The extend stage (src/trace.rs:12-23) for scenes with a BVH.  A traversal visits anything from
+// a handful to several hundred nodes, so dealing the active queue out in fixed portions leaves
+// most lanes of a wave waiting for its longest ray (measured on 10 000 objects: 46 node visits
+// per ray on average, 219 loop iterations per wave).  Here every lane fetches its next ray from
+// the queue when its current one is done (the waves of the workgroup share one counter in LDS),
+// and in every round the wave does what serves most lanes per instruction spent:
+//   * node steps for the lanes at an inner node,
+//   * the (kind-dependent, expensive) object test for the lanes holding a leaf,
+//   * service: finished rays are written back and queued by material, free lanes get their next
+//     ray, which starts with the always-tested list (planes).
+// Which lane traces which ray changes nothing: a ray's result goes to its own record.
+template <bool STATS, class SHAPE>
+RTX_DEV void wf_extend_bvh(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPixels> &L, const Table &tab, uint32_t cur_q,
+                           uint32_t nxt, int32_t *stacks, Counters<STATS> &cnt, uint32_t *dbg)
 {
-    using SHAPE = WfShape<LDS_STATE>;
+    constexpr int BLOCK = (int)SHAPE::kThreads;
+    constexpr uint32_t PLANE = SHAPE::kPlane;
+    constexpr uint32_t kNoRay = 0xffffffffu;
+    // one column per lane, P.bvh.stack_entries deep (the tree's depth + 1), in dynamic LDS
+    int32_t *stack = stacks + threadIdx.x;
+    const BvhView &B = P.bvh;
+    const uint32_t count = L.count[Q_ACTIVE0 + cur_q];
+    const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
+
+    uint32_t local = kNoRay;      // the lane's ray (workgroup-local pixel number) or none
+    int32_t cur = kBvhEmpty;      // traversal position; kBvhEmpty with a ray = finished, to be written back
+    int sp = 0, best = -1;
+    float best_t = kInf, ray_length = 0.0f;
+    V3 o = v3(0.0f, 0.0f, 0.0f), d = o;
+    BvhRay R;
+    R.inv = R.oi_lo = R.oi_hi = o;
+    R.far = false;
+    bool plain = true;
+    bool exhausted = false;       // wave-uniform: the queue has been handed out completely
+    for (;;) {
+        const bool at_leaf = cur < 0 && cur != kBvhEmpty;
+        const uint32_t n_node = (uint32_t)__popcll(__ballot(cur >= 0));
+        const uint32_t n_leaf = (uint32_t)__popcll(__ballot(at_leaf));
+        // lanes a service round would serve: finished rays, and free lanes while rays are left
+        const uint32_t n_done = (uint32_t)__popcll(__ballot(local != kNoRay && cur == kBvhEmpty));
+        const uint32_t n_serve = exhausted ? n_done : 64u - n_node - n_leaf;
+        if (n_node + n_leaf + n_serve == 0u) break;
+        // lanes served per unit of cost, compared by cross-multiplication
+        const uint32_t w_node = n_node * (RTX_WF_COST_LEAF * RTX_WF_COST_SERVE);
+        const uint32_t w_leaf = n_leaf * (RTX_WF_COST_NODE * RTX_WF_COST_SERVE);
+        const uint32_t w_serve = n_serve * (RTX_WF_COST_NODE * RTX_WF_COST_LEAF);
+        if (w_node >= w_leaf && w_node >= w_serve && n_node != 0u) {
+#pragma unroll
+            for (int k = 0; k < RTX_WF_NODE_BATCH; ++k) {
+                WF_DBG(D_NODE_ROUNDS, 1u);
+                WF_DBG(D_NODE_LANES, (uint32_t)__popcll(__ballot(cur >= 0)));
+                if (cur >= 0) bvh_node_step<STATS, BLOCK>(B, R, best_t, cur, sp, stack, cnt);
+            }
+        } else if (w_leaf >= w_serve && n_leaf != 0u) {
+            const bool leaves_plain = B.leaves_identity != 0u && __ballot(at_leaf && !plain) == 0ull;
+            WF_DBG(D_LEAF_ROUNDS, 1u);
+            WF_DBG(D_LEAF_LANES, n_leaf);
+            if (at_leaf) {
+                bvh_try_object<STATS>(tab, ~cur, o, d, ray_length, best, best_t, cnt, leaves_plain);
+                if (sp > 0) {
+                    sp--;
+                    cur = stack[sp * BLOCK];
+                } else {
+                    cur = kBvhEmpty;
+                }
+            }
+        } else {
+            // ---- write back the finished rays
+            WF_DBG(D_SERVE_ROUNDS, 1u);
+            WF_DBG(D_SERVE_DONE, n_done);
+            int material = -1;
+            bool refresh = false;
+            const uint32_t mine = local;
+            if (local != kNoRay && cur == kBvhEmpty) {
+                uint32_t px, py;
+                wf_pixel<SHAPE::kTiles>(P, local, px, py);
+                const uint32_t pixel = py * P.width + px;
+                const float4 c = rec[wf_at<PLANE>(local, 2)], e = rec[wf_at<PLANE>(local, 3)];
+                Path p;
+                p.o = o;
+                p.d = d;
+                p.T = v3(c.x, c.y, c.z);
+                p.depth = __float_as_uint(c.w);
+                p.L = v3(e.x, e.y, e.z);
+                const uint32_t sample = __float_as_uint(e.w);
+                cnt.template add<C_RAYS>();
+                bool done;
+                if (best < 0) {
+                    p.L = p.L + cmul(p.T, bg);
+                    done = true;
+                } else {
+                    if constexpr (STATS) {
+                        int kind = __float_as_int(tab.geom[3 * best + 1].w) & 0xff;
+                        cnt.template add<C_HIT_PLANE>(kind == kPlane);
+                        cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
+                        cnt.template add<C_HIT_BOX>(kind == kBox);
+                    }
+                    done = surface_emission(P, tab, p, best) || black_surface_ends(P, tab, p, best);
+                }
+                if (done) {
+                    refresh = wf_finish_path<PLANE>(P, rec, local, pixel, p.L, sample);
+                } else {
+                    wf_store_rad<PLANE>(rec, local, p.L, sample);
+                    wf_store_ray<PLANE>(rec, local, p, best_t, best);
+                    material = __float_as_int(tab.mat[3 * best + 0].w);
+                }
+                local = kNoRay;
+            }
+            wf_push(L, Q_FRESH0 + nxt, refresh, mine);
+            wf_push(L, Q_DIFFUSE, material == kDiffuse, mine);
+            wf_push(L, Q_METALLIC, material == kMetallic, mine);
+            wf_push(L, Q_DIELECTRIC, material == kDielectric, mine);
+            // ---- hand the free lanes their next rays
+            if (!exhausted) {
+                const bool want = local == kNoRay;
+                const unsigned long long mask = __ballot(want);   // not empty: this round serves at least one lane
+                const uint32_t n = (uint32_t)__popcll(mask);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                const int leader = __builtin_ctzll(mask);
+                uint32_t base = 0;
+                if ((int)(threadIdx.x & 63u) == leader) base = atomicAdd(&L.next, n);
+                base = (uint32_t)__shfl((int)base, leader, 64);
+                exhausted = base + n >= count;
+                const bool fresh = want && base + rank < count;
+                WF_DBG(D_SERVE_FETCHED, (uint32_t)__popcll(__ballot(fresh)));
+                bool fresh_plain = true;
+                if (fresh) {
+                    local = L.queue[Q_ACTIVE0 + cur_q][base + rank];
+                    const float4 a = rec[wf_at<PLANE>(local, 0)], b = rec[wf_at<PLANE>(local, 1)];
+                    o = v3(a.x, a.y, a.z);
+                    d = v3(b.x, b.y, b.z);
+                    fresh_plain = ray_is_plain(o, d);
+                }
+                // the shortcuts of the always-tested list need every ray of this batch to be plain
+                const bool all_plain = __ballot(!fresh_plain) == 0ull;
+                if (fresh) {
+                    plain = fresh_plain;
+                    ray_length = len(d);
+                    best = -1;
+                    best_t = kInf;
+                    for (uint32_t i = 0; i < B.n_planes; ++i)
+                        bvh_try_object<STATS, true>(tab, B.planes[i], o, d, ray_length, best, best_t, cnt, all_plain);
+                    R = bvh_ray_setup(B, o, d);
+                    sp = 0;
+                    cur = B.n_nodes ? 0 : kBvhEmpty;
+                }
+            }
+        }
+    }
+}
+
+template <int SRC, bool STATS, bool MANY_LIGHTS, class SHAPE>
+__global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParams P, const WfState S)
+{
+    constexpr bool LDS_STATE = SHAPE::kLdsState;
     constexpr uint32_t kWfThreads = SHAPE::kThreads, kWfPixelsPerGroup = SHAPE::kPixels;
-    // dynamic LDS: [queues + counters][records when LDS_STATE][object table when SRC == kSrcLds]
+    // dynamic LDS: [queues + counters][records when LDS_STATE][object table when SRC == kSrcLds | traversal stacks when SRC == kSrcBvh]
     WfLds<kWfPixelsPerGroup> &L = *reinterpret_cast<WfLds<kWfPixelsPerGroup> *>(rtx_smem);
     constexpr uint32_t kQueueVec = (sizeof(WfLds<kWfPixelsPerGroup>) + 15u) / 16u;
     constexpr uint32_t kRecVec = LDS_STATE ? 4u * kWfPixelsPerGroup : 0u;
@@ -213,6 +418,8 @@ __global__ void __launch_bounds__(WfShape<LDS_STATE>::kThreads) k_wavefront(cons
     const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
     Counters<STATS> cnt;
     cnt.clear();
+    uint32_t dbg[D_COUNT] = {};
+    (void)dbg;
 
     // every pixel of the workgroup starts in the fresh queue with a zero sum
     for (uint32_t base = 0; base < kWfPixelsPerGroup; base += kWfThreads) {
@@ -240,6 +447,7 @@ __global__ void __launch_bounds__(WfShape<LDS_STATE>::kThreads) k_wavefront(cons
             L.count[Q_DIFFUSE] = 0u;
             L.count[Q_METALLIC] = 0u;
             L.count[Q_DIELECTRIC] = 0u;
+            L.next = 0u;
         }
         __syncthreads();
 
@@ -249,6 +457,8 @@ __global__ void __launch_bounds__(WfShape<LDS_STATE>::kThreads) k_wavefront(cons
             for (uint32_t base = 0; base < count; base += kWfThreads) {
                 const uint32_t i = base + threadIdx.x;
                 const bool valid = i < count;
+                WF_DBG(D_GEN_ROUNDS, 1u);
+                WF_DBG(D_GEN_LANES, (uint32_t)__popcll(__ballot(valid)));
                 uint32_t local = 0;
                 if (valid) {
                     local = L.queue[Q_FRESH0 + cur][i];
@@ -272,7 +482,9 @@ __global__ void __launch_bounds__(WfShape<LDS_STATE>::kThreads) k_wavefront(cons
         __syncthreads();
 
         // ---- extend: src/trace.rs:12-23
-        {
+        if constexpr (SRC == kSrcBvh) {
+            wf_extend_bvh<STATS, SHAPE>(P, rec, L, tab, cur, nxt, reinterpret_cast<int32_t *>(rtx_smem + kQueueVec + kRecVec), cnt, dbg);
+        } else {
             const uint32_t count = L.count[Q_ACTIVE0 + cur];
             for (uint32_t base = 0; base < count; base += kWfThreads) {
                 const uint32_t i = base + threadIdx.x;
@@ -290,8 +502,7 @@ __global__ void __launch_bounds__(WfShape<LDS_STATE>::kThreads) k_wavefront(cons
                     cnt.template add<C_RAYS>();
                     float t;
                     int idx;
-                    if constexpr (SRC == kSrcBvh) idx = closest_hit_bvh<STATS, (int)kWfThreads>(P.bvh, tab, p.o, p.d, t, cnt);
-                    else idx = closest_hit_scan<true>(tab, p.o, p.d, t);
+                    idx = closest_hit_scan<true>(tab, p.o, p.d, t);
                     bool done;
                     if (idx < 0) {
                         p.L = p.L + cmul(p.T, bg);
@@ -322,11 +533,12 @@ __global__ void __launch_bounds__(WfShape<LDS_STATE>::kThreads) k_wavefront(cons
         __syncthreads();
 
         // ---- shade, one material at a time
-        wf_shade<kDiffuse, STATS, MANY_LIGHTS, SHAPE>(P, rec, L, tab, nxt, cnt);
-        wf_shade<kMetallic, STATS, MANY_LIGHTS, SHAPE>(P, rec, L, tab, nxt, cnt);
-        wf_shade<kDielectric, STATS, MANY_LIGHTS, SHAPE>(P, rec, L, tab, nxt, cnt);
+        wf_shade<kDiffuse, STATS, MANY_LIGHTS, SHAPE>(P, rec, L, tab, nxt, cnt, dbg);
+        wf_shade<kMetallic, STATS, MANY_LIGHTS, SHAPE>(P, rec, L, tab, nxt, cnt, dbg);
+        wf_shade<kDielectric, STATS, MANY_LIGHTS, SHAPE>(P, rec, L, tab, nxt, cnt, dbg);
         __syncthreads();
 
+        WF_DBG(D_ITERATIONS, 1u);
         if (L.count[Q_ACTIVE0 + nxt] + L.count[Q_FRESH0 + nxt] == 0u) break;
         __syncthreads();  // the counters are reset at the top of the next iteration
     }
@@ -336,15 +548,29 @@ __global__ void __launch_bounds__(WfShape<LDS_STATE>::kThreads) k_wavefront(cons
         for (int i = 0; i < C_COUNT; ++i)
             if (cnt.v[i]) atomicAdd(&P.stats[i], (unsigned long long)cnt.v[i]);
     }
+#ifdef RTX_WF_DEBUG
+    if ((threadIdx.x & 63u) == 0u)
+        for (int i = 0; i < D_COUNT; ++i) atomicAdd(&g_wf_dbg[i], (unsigned long long)dbg[i]);
+#endif
 }
 
 }  // namespace
 
-// the HBM-state shape decides the size of the state block (the LDS-state shape needs none)
+#ifdef RTX_WF_DEBUG
+extern "C" int rtx_wf_debug_read(unsigned long long *out, int reset)
+{
+    unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wf_dbg), sizeof(zero)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_wf_dbg), zero, sizeof(zero)) != hipSuccess) return -1;
+    return D_COUNT;
+}
+#endif
+
+// the HBM-state shape decides the size of the state block (the LDS-state shapes need none)
 static uint32_t wavefront_slots(uint32_t width, uint32_t height)
 {
     const uint32_t tiles = ((width + 7u) / 8u) * ((height + 7u) / 8u);
-    return (tiles + WfShape<false>::kTiles - 1u) / WfShape<false>::kTiles * WfShape<false>::kPixels;
+    return (tiles + ShapeBvhHbm::kTiles - 1u) / ShapeBvhHbm::kTiles * ShapeBvhHbm::kPixels;
 }
 
 size_t wavefront_state_bytes(uint32_t width, uint32_t height)
@@ -358,55 +584,63 @@ void wavefront_bind_state(void *block, uint32_t, uint32_t, WfState &S)
 }
 
 // LDS a workgroup of the given shape needs: queues, records (LDS state), object table (kSrcLds)
-template <bool LDS_STATE>
+// or traversal stacks (kSrcBvh)
+template <class SHAPE>
 static size_t wavefront_lds_bytes(const RenderParams &P, int src)
 {
-    size_t lds = (sizeof(WfLds<WfShape<LDS_STATE>::kPixels>) + 15u) / 16u * 16u;
-    if (LDS_STATE) lds += (size_t)WfShape<true>::kPixels * 4u * sizeof(float4);
+    size_t lds = (sizeof(WfLds<SHAPE::kPixels>) + 15u) / 16u * 16u;
+    if (SHAPE::kLdsState) lds += (size_t)SHAPE::kPixels * 4u * sizeof(float4);
     if (src == kSrcLds) lds += scene_lds_bytes(P.n_prims, P.n_lights);
+    if (src == kSrcBvh) lds += (size_t)P.bvh.stack_entries * SHAPE::kThreads * sizeof(int32_t);
     return lds;
 }
-// two workgroups per CU (160 KB of LDS on gfx950): while one waits at a barrier or runs out of
-// paths near its end, the other keeps the SIMDs busy (one workgroup of 1024 threads and 2048
-// pixels per CU measured 93.7 ms on the reference scene at 1080p, two of 512 / 1024: 88.2 ms)
-constexpr size_t kMaxLdsPerWorkgroup = 80u * 1024u;
+// Linear scan: two workgroups per CU (160 KB of LDS on gfx950): while one waits at a barrier or
+// runs out of paths near its end, the other keeps the SIMDs busy (one workgroup of 1024 threads
+// and 2048 pixels per CU measured 93.7 ms on the reference scene at 1080p, two of 512 / 1024: 88.2 ms)
+constexpr size_t kMaxLdsScan = 80u * 1024u;
+// BVH, records in LDS: one-wave workgroups, at least 12 of them per CU (3 waves per SIMD)
+#ifndef RTX_WF_BVH_LDS_MAX
+#define RTX_WF_BVH_LDS_MAX (160u * 1024u / 12u)
+#endif
 
-bool wavefront_state_in_lds(const RenderParams &, int src)
+bool wavefront_state_in_lds(const RenderParams &P, int src)
 {
-    return src != kSrcBvh;
+    return src != kSrcBvh || wavefront_lds_bytes<ShapeBvhLds>(P, kSrcBvh) <= RTX_WF_BVH_LDS_MAX;
 }
 
-template <int SRC, bool STATS, bool MANY_LIGHTS, bool LDS_STATE>
+template <int SRC, bool STATS, bool MANY_LIGHTS, class SHAPE>
 static hipError_t launch_variant(const RenderParams &P, const WfState &S, hipStream_t stream)
 {
-    using SHAPE = WfShape<LDS_STATE>;
     const uint32_t tiles = ((P.width + 7u) / 8u) * ((P.height + 7u) / 8u);
     const dim3 grid((tiles + SHAPE::kTiles - 1u) / SHAPE::kTiles);
-    const size_t lds = wavefront_lds_bytes<LDS_STATE>(P, SRC);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wavefront<SRC, STATS, MANY_LIGHTS, LDS_STATE>),
+    const size_t lds = wavefront_lds_bytes<SHAPE>(P, SRC);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wavefront<SRC, STATS, MANY_LIGHTS, SHAPE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_wavefront<SRC, STATS, MANY_LIGHTS, LDS_STATE>), grid, dim3(SHAPE::kThreads), lds, stream, P, S);
+    hipLaunchKernelGGL((k_wavefront<SRC, STATS, MANY_LIGHTS, SHAPE>), grid, dim3(SHAPE::kThreads), lds, stream, P, S);
     return hipGetLastError();
 }
-template <int SRC, bool STATS, bool LDS_STATE>
+template <int SRC, bool STATS, class SHAPE>
 static hipError_t launch_one(const RenderParams &P, const WfState &S, hipStream_t stream)
 {
-    return P.n_lights > kFewLights ? launch_variant<SRC, STATS, true, LDS_STATE>(P, S, stream)
-                                   : launch_variant<SRC, STATS, false, LDS_STATE>(P, S, stream);
+    return P.n_lights > kFewLights ? launch_variant<SRC, STATS, true, SHAPE>(P, S, stream)
+                                   : launch_variant<SRC, STATS, false, SHAPE>(P, S, stream);
 }
-template <int SRC, bool LDS_STATE>
+template <int SRC, class SHAPE>
 static hipError_t launch_src(const RenderParams &P, const WfState &S, bool stats, hipStream_t stream)
 {
-    return stats ? launch_one<SRC, true, LDS_STATE>(P, S, stream) : launch_one<SRC, false, LDS_STATE>(P, S, stream);
+    return stats ? launch_one<SRC, true, SHAPE>(P, S, stream) : launch_one<SRC, false, SHAPE>(P, S, stream);
 }
 
 hipError_t launch_wavefront(const RenderParams &P, const WfState &S, int src, bool stats, hipStream_t stream)
 {
-    if (src == kSrcBvh) return launch_src<kSrcBvh, false>(P, S, stats, stream);
-    if (src == kSrcLds && wavefront_lds_bytes<true>(P, kSrcLds) <= kMaxLdsPerWorkgroup)
-        return launch_src<kSrcLds, true>(P, S, stats, stream);
-    return launch_src<kSrcScalar, true>(P, S, stats, stream);
+    if (src == kSrcBvh) {
+        if (wavefront_state_in_lds(P, kSrcBvh)) return launch_src<kSrcBvh, ShapeBvhLds>(P, S, stats, stream);
+        return launch_src<kSrcBvh, ShapeBvhHbm>(P, S, stats, stream);
+    }
+    if (src == kSrcLds && wavefront_lds_bytes<ShapeScan>(P, kSrcLds) <= kMaxLdsScan)
+        return launch_src<kSrcLds, ShapeScan>(P, S, stats, stream);
+    return launch_src<kSrcScalar, ShapeScan>(P, S, stats, stream);
 }
 
 }  // namespace rtx
