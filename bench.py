@@ -8,6 +8,11 @@ HIP kernels, the per-GPU radiance sums combined (RCCL all-reduce when N > 1) and
 divided by the sample count.  The scene and the output buffer are resident in HBM
 before the timed region starts.
 
+With no --workload and N = 1 the line also carries, under "workloads", the other configurations
+(3 steps each, timed the same way): c4 on one GPU -- the base the multi-GPU runs of c4 compare
+with --, c3 and c5 with both kernels, c2 with the wavefront kernel.  All GPU work runs in one
+block before the CPU baseline.
+
 Workloads:
   c2  reference scene at 1920x1080, 256 spp, depth 6, seed 1      (default for N = 1)
   c4  reference scene at 3840x2160, 1024 spp, samples split over the N GPUs
@@ -95,6 +100,107 @@ def measured_traffic(workload, mode, n_gpus):
     return (2.0 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024.0, os.path.relpath(files[-1], ROOT)
 
 
+def measure(name, mode_name, accel_name, steps, warmup, seed, rank, world, local_rank, use_dist, want_stats=True,
+            spp=None, size=None, depth=None, stats_spp=None):
+    """Times `steps` steps of one workload on this rank's GPU (scene and buffers resident in HBM before
+    the timed region, barrier + synchronize on both sides, max over ranks) and counts its path events
+    in an untimed launch.  stats_spp: count the events on that many samples per pixel only and scale
+    (for workloads whose counting launch would take seconds)."""
+    import torch
+    import torch.distributed as dist
+    from raytracing_amd import _abi
+    from raytracing_amd.renderer import Renderer
+    from raytracing_amd.flops import (algorithmic_flops, PEAK_FP32_VECTOR_TFLOPS, PEAK_FP32_NONPACKED_TFLOPS)
+    from raytracing_amd.parallel import sample_range
+
+    scene, desc = build_workload(name, spp, size)
+    if depth is not None:
+        scene = scene.replace(ray_depth=depth)
+        desc += f" [depth overridden to {depth}]"
+    mode = {"megakernel": _abi.MODE_MEGAKERNEL, "wavefront": _abi.MODE_WAVEFRONT}[mode_name]
+    accel = {"auto": _abi.ACCEL_AUTO, "lds": _abi.ACCEL_BRUTE_LDS, "scalar": _abi.ACCEL_BRUTE_SCALAR,
+             "bvh": _abi.ACCEL_BVH}[accel_name]
+    first, count = sample_range(scene.n_samples, rank, world)
+    n_floats = scene.width * scene.height * 3
+    buf = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    r = Renderer(seed=seed, mode=mode, accel=accel, device=local_rank)
+    r.set_scene(scene)
+
+    def step(ev=None):
+        if ev:
+            ev[0].record()
+        r.render_samples(first, count, buf.data_ptr(), stream)
+        if ev:
+            ev[1].record()
+        if use_dist:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        r.divide(buf.data_ptr(), n_floats, float(scene.n_samples), stream)
+
+    for _ in range(warmup):
+        step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(events[k])
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, steps)
+    checksum = float(buf.double().sum().item())
+    r.close()
+
+    # event counters of this rank's share: an untimed launch of the counting kernels on
+    # the same inputs (paths are deterministic, so the events are those of a timed step)
+    total_samples = scene.width * scene.height * scene.n_samples
+    res = {"workload": f"{name}: {desc}", "mode": mode_name, "accel": accel_name, "ms_per_step": elapsed / steps * 1e3,
+           "msamples_per_s": total_samples * steps / elapsed / 1e6, "kernel_ms": kernel_ms, "steps": steps,
+           "samples_per_step": total_samples, "checksum": checksum, "elapsed": elapsed}
+    if want_stats:
+        rs = Renderer(seed=seed, mode=mode, accel=accel, device=local_rank, collect_stats=True)
+        rs.set_scene(scene)
+        n_counted = count if not stats_spp else min(count, stats_spp)
+        rs.render_samples(first, n_counted, buf.data_ptr(), stream)
+        torch.cuda.synchronize()
+        stats = rs.stats()
+        rs.close()
+        scale = count / max(1, n_counted)
+        flops_rank = algorithmic_flops(stats, stats.get("bvh_node_tests", 0)) * scale
+        achieved = flops_rank / (kernel_ms * 1e-3) / 1e12
+        rays = torch.tensor([stats["rays"] * scale], dtype=torch.float64, device="cuda")
+        if use_dist:
+            dist.all_reduce(rays, op=dist.ReduceOp.SUM)
+        res.update({"algorithmic_tflops": achieved, "frac": achieved / PEAK_FP32_VECTOR_TFLOPS,
+                    "frac_of_nonpacked_fma_peak": achieved / PEAK_FP32_NONPACKED_TFLOPS,
+                    "algorithmic_flops_per_launch": flops_rank,
+                    "flops_per_sample": flops_rank / max(1, stats["samples"] * scale),
+                    "rays_per_sample": stats["rays"] / max(1, stats["samples"]),
+                    "mrays_per_s": float(rays.item()) * steps / elapsed / 1e6,
+                    "events_counted_on_spp": n_counted})
+    return res
+
+
+def profile_files(workload, mode):
+    """The committed rocprofv3 summaries of this workload (thread-active fraction, HBM bytes)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", f"{workload}_{mode}_pmc.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return {"source": os.path.relpath(files[-1], ROOT), "thread_active_fraction": d.get("thread_active_fraction"),
+            "hbm_bytes_per_step": d.get("hbm_bytes_per_launch")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,14 +215,12 @@ def main():
     ap.add_argument("--depth", type=int, default=None, help="override RAY_DEPTH (experiments only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="N = 1: only the headline workload, not the other configurations")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from raytracing_amd import _abi
-    from raytracing_amd.renderer import Renderer
-    from raytracing_amd.flops import (algorithmic_flops, PEAK_FP32_VECTOR_TFLOPS, PEAK_FP32_NONPACKED_TFLOPS)
-    from raytracing_amd.parallel import sample_range
+    from raytracing_amd.flops import PEAK_FP32_VECTOR_TFLOPS
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,103 +237,57 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     name = args.workload or ("c2" if world == 1 else "c4")
-    scene, desc = build_workload(name, args.spp, args.size)
-    if args.depth is not None:
-        scene = scene.replace(ray_depth=args.depth)
-        desc += f" [depth overridden to {args.depth}]"
-    mode = {"megakernel": _abi.MODE_MEGAKERNEL, "wavefront": _abi.MODE_WAVEFRONT}[args.mode]
-    accel = {"auto": _abi.ACCEL_AUTO, "lds": _abi.ACCEL_BRUTE_LDS, "scalar": _abi.ACCEL_BRUTE_SCALAR,
-             "bvh": _abi.ACCEL_BVH}[args.accel]
-    first, count = sample_range(scene.n_samples, rank, world)
-    n_floats = scene.width * scene.height * 3
-    buf = torch.zeros(n_floats, dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream().cuda_stream
+    common = dict(seed=args.seed, rank=rank, world=world, local_rank=local_rank, use_dist=use_dist)
+    head = measure(name, args.mode, args.accel, args.steps, args.warmup, want_stats=not args.no_stats, spp=args.spp,
+                   size=args.size, depth=args.depth, stats_spp=64 if name == "c4" else None, **common)
 
-    r = Renderer(seed=args.seed, mode=mode, accel=accel, device=local_rank)
-    r.set_scene(scene)
-
-    def step(ev=None):
-        if ev:
-            ev[0].record()
-        r.render_samples(first, count, buf.data_ptr(), stream)
-        if ev:
-            ev[1].record()
-        if use_dist:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        r.divide(buf.data_ptr(), n_floats, float(scene.n_samples), stream)
-
-    for _ in range(args.warmup):
-        step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(events[k])
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
-    checksum = float(buf.double().sum().item())
-
-    # event counters of this rank's share: an untimed launch of the counting kernels on
-    # the same inputs (paths are deterministic, so the events are those of a timed step)
-    stats = None
-    if not args.no_stats:
-        rs = Renderer(seed=args.seed, mode=mode, accel=accel, device=local_rank, collect_stats=True)
-        rs.set_scene(scene)
-        rs.render_samples(first, count, buf.data_ptr(), stream)
-        torch.cuda.synchronize()
-        stats = rs.stats()
-        rs.close()
-    total_samples = scene.width * scene.height * scene.n_samples
-    rays_total = None
-    roofline = None
-    if stats is not None:
-        flops_rank = algorithmic_flops(stats, stats.get("bvh_node_tests", 0))
-        achieved = flops_rank / (kernel_ms * 1e-3) / 1e12
-        traffic, traffic_src = measured_traffic(name, args.mode, world)
-        roofline = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_VECTOR_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / PEAK_FP32_VECTOR_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
-                    "frac_of_nonpacked_fma_peak": achieved / PEAK_FP32_NONPACKED_TFLOPS,
-                    "kernel": ("k_megakernel (probe launch of 8 samples, k_tile_order, main launch in cost order)"
-                               if mode == _abi.MODE_MEGAKERNEL else "k_wavefront"),
-                    "kernel_ms": kernel_ms, "algorithmic_flops_per_launch": flops_rank,
-                    "flops_per_sample": flops_rank / max(1, stats["samples"]),
-                    "rays_per_sample": stats["rays"] / max(1, stats["samples"])}
-        rays = torch.tensor([stats["rays"]], dtype=torch.float64, device="cuda")
-        if use_dist:
-            dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-        rays_total = float(rays.item())
+    # N = 1, default workload: the other configurations in the same run, all GPU work in one block
+    # before the CPU baseline.  c4 on one GPU is the base the multi-GPU runs of c4 compare with.
+    extra = {}
+    if world == 1 and args.workload is None and not args.no_extra:
+        for key, wl, mode, steps, sspp in (("c4_single_gpu", "c4", "megakernel", 3, 64), ("c3", "c3", "megakernel", 3, None),
+                                           ("c3_wavefront", "c3", "wavefront", 3, None), ("c5", "c5", "megakernel", 3, None),
+                                           ("c5_wavefront", "c5", "wavefront", 3, None), ("c2_wavefront", "c2", "wavefront", 3, None)):
+            m = measure(wl, mode, "auto", steps, 1, want_stats=not args.no_stats, stats_spp=sspp, **common)
+            m.pop("elapsed")
+            m["profile"] = profile_files(wl, mode)
+            extra[key] = m
 
     if rank == 0:
-        value = total_samples * args.steps / elapsed / 1e6
+        total_samples = head["samples_per_step"]
+        value = total_samples * args.steps / head["elapsed"] / 1e6
         out = {
             "metric": "Msamples/sec (whole node)", "value": value, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "ms_per_step": head["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{name}: {desc}", "mode": args.mode, "accel": args.accel, "seed": args.seed,
+            "dtype": "f32", "data": "synthetic" if name in ("c3", "c5") else "the reference's assets/scene.txt, restated",
+            "config": {"workload": head["workload"], "mode": args.mode, "accel": args.accel, "seed": args.seed,
                        "samples_per_step": total_samples,
                        "parallelism": f"spp-split x{world} + all-reduce" if world > 1 else "single GPU"},
-            "mrays_per_s": (rays_total * args.steps / elapsed / 1e6) if rays_total else None,
-            "checksum": checksum,
+            "mrays_per_s": head.get("mrays_per_s"),
+            "checksum": head["checksum"],
         }
-        if roofline:
-            out["roofline"] = roofline
+        if "frac" in head:
+            traffic, traffic_src = measured_traffic(name, args.mode, world)
+            out["roofline"] = {"bound": "valu", "achieved": head["algorithmic_tflops"], "peak": PEAK_FP32_VECTOR_TFLOPS,
+                               "unit": "TFLOP/s", "frac": head["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                               "frac_of_nonpacked_fma_peak": head["frac_of_nonpacked_fma_peak"],
+                               "kernel": ("k_megakernel (probe launch of 8 samples, k_tile_order, main launch in cost order)"
+                                          if args.mode == "megakernel" else "k_wavefront"),
+                               "kernel_ms": head["kernel_ms"], "algorithmic_flops_per_launch": head["algorithmic_flops_per_launch"],
+                               "flops_per_sample": head["flops_per_sample"], "rays_per_sample": head["rays_per_sample"],
+                               "events_counted_on_spp": head["events_counted_on_spp"]}
+        if extra:
+            out["workloads"] = extra
+            out["c4_single_gpu"] = {k: extra["c4_single_gpu"][k] for k in ("ms_per_step", "msamples_per_s", "frac", "mrays_per_s")
+                                    if k in extra["c4_single_gpu"]}
         if world == 1 and not args.no_cpu_baseline:
+            scene, _ = build_workload(name, args.spp, args.size)
             cb = cpu_baseline(scene)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_1thread"] = value / cb["value"]
         print(json.dumps(out), flush=True)
-    r.close()
     if use_dist:
         dist.destroy_process_group()
 

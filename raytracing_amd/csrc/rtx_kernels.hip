@@ -106,10 +106,10 @@ RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, flo
 #define RTX_MK_TRAV_DEN 4u
 #endif
 #ifndef RTX_MK_LEAF_COST
-#define RTX_MK_LEAF_COST 3u
+#define RTX_MK_LEAF_COST 2u
 #endif
 #ifndef RTX_MK_NODE_BATCH
-#define RTX_MK_NODE_BATCH 2
+#define RTX_MK_NODE_BATCH 4
 #endif
 #ifndef RTX_MEGAKERNEL_ATTR
 #define RTX_MEGAKERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))  // at most 128 VGPRs: 4 waves per SIMD measured fastest for the scan and the BVH kernels alike
