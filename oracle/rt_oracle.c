@@ -53,10 +53,20 @@ static inline v3 div3(v3 a, v3 b) { return V(a.x / b.x, a.y / b.y, a.z / b.z); }
 static inline v3 scale3(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
 static inline v3 unscale3(v3 a, float s) { return V(a.x / s, a.y / s, a.z / s); }
 static inline v3 neg3(v3 a) { return V(-a.x, -a.y, -a.z); }
+/* ORC_ALT_*: other plausible operation orders of the dependency kernels, for measuring how much
+ * hangs on the recalled ones (oracle/Makefile: alternatives; tests/test_order_fragility.py). */
+#ifdef ORC_ALT_DOT
+static inline float dot3(v3 a, v3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+#else
 static inline float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+#endif
 static inline float length2_3(v3 a) { return dot3(a, a); }
 static inline float length3(v3 a) { return sqrtf(dot3(a, a)); }
+#ifdef ORC_ALT_NORMALIZE
+static inline v3 normalize3(v3 a) { return scale3(a, 1.0f / length3(a)); }
+#else
 static inline v3 normalize3(v3 a) { return unscale3(a, length3(a)); }
+#endif
 static inline v3 cross3(v3 a, v3 b)
 {
     return V(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
@@ -86,7 +96,11 @@ static inline v3 quat_rotate(const float q[4], v3 v)
     v3 u = V(q[0], q[1], q[2]);
     v3 t = scale3(cross3(u, v), 2.0f);
     v3 c = cross3(u, t);
+#ifdef ORC_ALT_QUAT
+    return add3(add3(v, scale3(t, q[3])), c);
+#else
     return add3(add3(scale3(t, q[3]), c), v);
+#endif
 }
 static inline v3 quat_rotate_inv(const float q[4], v3 v)
 {
@@ -96,9 +110,15 @@ static inline v3 quat_rotate_inv(const float q[4], v3 v)
 /* column-major 3x3 times vector */
 static inline v3 mat3_mul(const float m[9], v3 v)
 {
+#ifdef ORC_ALT_MATVEC
+    return V(m[0] * v.x + (m[3] * v.y + m[6] * v.z),
+             m[1] * v.x + (m[4] * v.y + m[7] * v.z),
+             m[2] * v.x + (m[5] * v.y + m[8] * v.z));
+#else
     return V((m[0] * v.x + m[3] * v.y) + m[6] * v.z,
              (m[1] * v.x + m[4] * v.y) + m[7] * v.z,
              (m[2] * v.x + m[5] * v.y) + m[8] * v.z);
+#endif
 }
 
 /* --------------------------------------------------------------------- rays */

@@ -15,21 +15,21 @@
 #include <cstring>
 #include <fstream>
 #include <sstream>
+#include <new>
 #include <string>
 #include <vector>
 
 namespace {
 
-thread_local std::string g_error;
+// fixed storage: reporting an error must not allocate (it may be reporting an allocation failure)
+thread_local char g_error[512] = "";
 
 int fail(int code, const char *fmt, ...)
 {
-    char buf[512];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof(buf), fmt, ap);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
     va_end(ap);
-    g_error = buf;
     return code;
 }
 
@@ -271,21 +271,34 @@ int parse_stream(std::istream &in, rtx_host_scene *out)
 
 extern "C" {
 
-const char *rtx_host_last_error(void) { return g_error.c_str(); }
+const char *rtx_host_last_error(void) { return g_error; }
 
+// no exception crosses the C boundary: running out of memory is a status code
 int rtx_host_parse_file(const char *path, rtx_host_scene *out)
 {
     if (!path || !out) return fail(RTX_ERR_INVALID_ARG, "null argument");
-    std::ifstream f(path);
-    if (!f) return fail(RTX_ERR_INVALID_SCENE, "cannot open %s", path);
-    return parse_stream(f, out);
+    try {
+        std::ifstream f(path);
+        if (!f) return fail(RTX_ERR_INVALID_SCENE, "cannot open %s", path);
+        return parse_stream(f, out);
+    } catch (const std::bad_alloc &) {
+        return fail(RTX_ERR_NO_MEMORY, "out of memory while parsing %s", path);
+    } catch (...) {
+        return fail(RTX_ERR_INVALID_SCENE, "unexpected exception while parsing %s", path);
+    }
 }
 
 int rtx_host_parse_text(const char *text, rtx_host_scene *out)
 {
     if (!text || !out) return fail(RTX_ERR_INVALID_ARG, "null argument");
-    std::istringstream s{std::string(text)};
-    return parse_stream(s, out);
+    try {
+        std::istringstream s{std::string(text)};
+        return parse_stream(s, out);
+    } catch (const std::bad_alloc &) {
+        return fail(RTX_ERR_NO_MEMORY, "out of memory while parsing the scene text");
+    } catch (...) {
+        return fail(RTX_ERR_INVALID_SCENE, "unexpected exception while parsing the scene text");
+    }
 }
 
 void rtx_host_free_scene(rtx_host_scene *scene)
