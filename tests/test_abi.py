@@ -83,3 +83,20 @@ def test_rust_bindings_name_the_header_functions_and_fields():
         body = rs[rs.index(f"pub struct {name} {{"):]
         body = body[:body.index("\n}\n")]
         assert re.findall(r"pub ([a-z_0-9]+):", body) == [f for f, _ in ctype._fields_], name
+
+
+def test_host_patch_uses_the_header_names():
+    """integration/host_patch/ holds the Rust functions a maintainer adds to the reference; the
+    struct literals in them must name exactly the fields of the header's structs, in order."""
+    patch = os.path.join(ROOT, "integration", "host_patch")
+    main = open(os.path.join(patch, "main.rs")).read()
+    parser = open(os.path.join(patch, "parser.rs")).read()
+    body = main[main.index("rtx_sys::rtx_scene {"):]
+    body = body[:body.index("};")]
+    assert re.findall(r"\n\s+([a-z_0-9]+)(?::|,)", body) == [f for f, _ in _abi.rtx_scene._fields_]
+    body = parser[parser.index("rtx_sys::rtx_prim {"):]
+    body = body[:body.index("}\n")]
+    assert re.findall(r"\n\s+([a-z_0-9]+)(?::|,)", body) == [f for f, _ in _abi.rtx_prim._fields_]
+    for name in re.findall(r"rtx_sys::(RTX_[A-Z_0-9]+)", parser):
+        assert f"pub const {name}:" in open(os.path.join(ROOT, "integration", "rtx-sys", "src", "lib.rs")).read(), name
+    assert "n_devices: gpu_count()" in main and "ctx.render(" in main
