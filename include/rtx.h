@@ -176,7 +176,7 @@ int rtx_render_samples(rtx_ctx *ctx, uint32_t sample_first, uint32_t sample_coun
  * megakernel live in a static device array of RTX_STATIC_MAX_TILES * 8 bytes (2 MiB) that every
  * GPU the library runs on holds until the process ends.  RTX_ERR_UNSUPPORTED for an image of more
  * than RTX_STATIC_MAX_TILES tiles of 8 x 8 pixels (e.g. beyond 4096 x 4096) and for the wavefront
- * variant on a BVH scene (its path state is a device block).  All contexts on one GPU share that
+ * variant on a scene whose BVH is deep (its path state is then a device block).  All contexts on one GPU share that
  * GPU's array: calls that overlap in time on one GPU race, whatever their streams. */
 #define RTX_STATIC_MAX_TILES 262144u
 int rtx_render_samples_static(rtx_ctx *ctx, uint32_t sample_first, uint32_t sample_count,

@@ -837,7 +837,7 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
     if (no_alloc) {
         if (c->opts.mode == RTX_MODE_WAVEFRONT && !rtx::wavefront_state_in_lds(P, c->src))
             return fail(RTX_ERR_UNSUPPORTED,
-                        "rtx_render_samples_static: the wavefront variant keeps its path state in device memory for BVH scenes");
+                        "rtx_render_samples_static: the wavefront variant keeps its path state in device memory for scenes with a deep BVH");
         if (n_tiles > RTX_STATIC_MAX_TILES)
             return fail(RTX_ERR_UNSUPPORTED, "rtx_render_samples_static: %u x %u has %u tiles of 8 x 8 pixels, the static tables hold %u",
                         P.width, P.height, n_tiles, (unsigned)RTX_STATIC_MAX_TILES);

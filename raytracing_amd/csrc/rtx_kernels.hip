@@ -111,6 +111,15 @@ RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, flo
 #ifndef RTX_MK_NODE_BATCH
 #define RTX_MK_NODE_BATCH 4
 #endif
+// The diffuse scatter of a hit is postponed until NUM / 64 of the wave's active lanes wait for one
+// (0: the scatter is one call for all materials, as soon as the hit is known), separately for the
+// linear scan and the BVH kernels.
+#ifndef RTX_MK_DIFFUSE_SCAN
+#define RTX_MK_DIFFUSE_SCAN 1u
+#endif
+#ifndef RTX_MK_DIFFUSE_BVH
+#define RTX_MK_DIFFUSE_BVH 0u
+#endif
 #ifndef RTX_MEGAKERNEL_ATTR
 #define RTX_MEGAKERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))  // at most 128 VGPRs: 4 waves per SIMD measured fastest for the scan and the BVH kernels alike
 #endif
@@ -171,6 +180,22 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
     int sp = 0, best = -1;
     float best_t = kInf;
     bool trav = false;                                  // the current ray's closest hit is still being searched
+    constexpr uint32_t kDiffuseNum = SRC == kSrcBvh ? RTX_MK_DIFFUSE_BVH : RTX_MK_DIFFUSE_SCAN;
+    static_assert(kDiffuseNum <= 64u, "a threshold above all lanes would stall the wave");
+    bool wait_diffuse = false;                          // hit known (hit_idx, hit_t), diffuse scatter not yet done
+    int hit_idx = -1;
+    float hit_t = 0.0f;
+    auto finish_sample = [&]() {
+        if ((job & 63u) == (threadIdx.x & 63u)) {
+            sum = sum + p.L;
+        } else {
+            float4 *e = pool + (job >> 6);
+            e->x = p.L.x;
+            e->y = p.L.y;
+            e->z = p.L.z;
+        }
+        active = false;
+    };
     for (;;) {
         const uint32_t lane = threadIdx.x & 63u;
         bool fresh = false;
@@ -216,9 +241,11 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
         }
         float t = 0.0f;
         int idx = -1;
-        bool hit_known = active;      // the lane's closest hit is known: it goes on to the scatter
+        // a lane whose diffuse scatter is pending (below) has its hit already
+        const bool need_hit = active && !wait_diffuse;
+        bool hit_known = need_hit;    // the lane's closest hit is known: it goes on to the scatter
         if constexpr (SRC != kSrcBvh) {
-            if (active) {
+            if (need_hit) {
                 cnt.template add<C_RAYS>();
                 if constexpr (RECORD) rays += 1u;
                 idx = closest_hit_scan<true>(tab, p.o, p.d, t);
@@ -234,7 +261,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
             int32_t *stack = reinterpret_cast<int32_t *>(rtx_smem) + threadIdx.x;
             const bool plain = ray_is_plain(p.o, p.d);
             const float ray_length = len(p.d);
-            const bool starting = active && !trav;
+            const bool starting = need_hit && !trav;
             const bool all_plain = __ballot(starting && !plain) == 0ull;
             if (starting) {
                 cnt.template add<C_RAYS>();
@@ -274,7 +301,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
                     }
                 }
             }
-            hit_known = active && cur == kBvhEmpty;
+            hit_known = need_hit && cur == kBvhEmpty;
             if (hit_known) {
                 trav = false;
                 idx = best;
@@ -293,18 +320,36 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
                     cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
                     cnt.template add<C_HIT_BOX>(kind == kBox);
                 }
-                done = scatter<STATS, MANY_LIGHTS>(P, tab, p, idx, t, pixel, s, cnt);
-            }
-            if (done) {
-                if ((job & 63u) == lane) {
-                    sum = sum + p.L;
+                if constexpr (kDiffuseNum == 0u) {
+                    done = scatter<STATS, MANY_LIGHTS>(P, tab, p, idx, t, pixel, s, cnt);
                 } else {
-                    float4 *e = pool + (job >> 6);
-                    e->x = p.L.x;
-                    e->y = p.L.y;
-                    e->z = p.L.z;
+                    // emission, depth cut and the cheap materials at once; the diffuse scatter --
+                    // direction sampling and the light pdf, most of a surface interaction's cost --
+                    // waits until enough lanes of the wave want it
+                    done = surface_emission(P, tab, p, idx) || black_surface_ends(P, tab, p, idx);
+                    if (!done) {
+                        const int material = __float_as_int(tab.mat[3 * idx + 0].w);
+                        if (material == kDiffuse) {
+                            wait_diffuse = true;
+                            hit_idx = idx;
+                            hit_t = t;
+                        } else {
+                            done = bounce<STATS, MANY_LIGHTS>(P, tab, p, idx, t, material, pixel, s, cnt);
+                        }
+                    }
                 }
-                active = false;
+            }
+            if (done) finish_sample();
+        }
+        if constexpr (kDiffuseNum != 0u) {
+            const uint32_t n_wait = (uint32_t)__popcll(__ballot(wait_diffuse));
+            const uint32_t n_act = (uint32_t)__popcll(__ballot(active));
+            // every active lane waiting always satisfies this (kDiffuseNum <= 64): the wave cannot stall
+            if (n_wait != 0u && n_wait * 64u >= n_act * kDiffuseNum) {
+                if (wait_diffuse) {
+                    wait_diffuse = false;
+                    if (bounce<STATS, MANY_LIGHTS>(P, tab, p, hit_idx, hit_t, kDiffuse, pixel, s, cnt)) finish_sample();
+                }
             }
         }
     }

@@ -55,14 +55,17 @@ def test_static_entry_point_limits():
         with pytest.raises(RtxError) as e:
             r.render_samples_static(0, 1, buf.data_ptr(), 0)
         assert e.value.code == _abi.RTX_ERR_UNSUPPORTED and "tiles" in str(e.value)
-    # the wavefront variant on a BVH scene keeps its path state in a device block
+    # the wavefront variant keeps its path state in a device block when the BVH is deep (the
+    # traversal stacks then fill the LDS)
+    from raytracing_amd import synthetic_scene
     with Renderer(mode=_abi.MODE_WAVEFRONT, accel=_abi.ACCEL_BVH) as r:
-        r.set_scene(reference_scene(width=16, height=16, n_samples=1))
+        r.set_scene(synthetic_scene(n_prims=4000, seed=3, width=16, height=16, n_samples=1, ray_depth=3))
         with pytest.raises(RtxError) as e:
             r.render_samples_static(0, 1, buf.data_ptr(), 0)
         assert e.value.code == _abi.RTX_ERR_UNSUPPORTED
-    # ... and with its state in LDS it needs nothing
+    # ... and with its state in LDS (linear scan; BVH with a shallow tree) it needs nothing
     sc = reference_scene(width=40, height=24, n_samples=5)
-    with Renderer(seed=3, mode=_abi.MODE_WAVEFRONT, accel=_abi.ACCEL_BRUTE_LDS) as r:
-        want, got = _both(r, sc, torch)
-        assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    for accel in (_abi.ACCEL_BRUTE_LDS, _abi.ACCEL_BVH):
+        with Renderer(seed=3, mode=_abi.MODE_WAVEFRONT, accel=accel) as r:
+            want, got = _both(r, sc, torch)
+            assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
