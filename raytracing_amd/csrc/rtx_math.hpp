@@ -31,6 +31,11 @@ typedef float F2 __attribute__((ext_vector_type(2)));
 // the two quotients run as packed instructions (v_pk_fma_f32: 5.5 cycles for both against 4.1 each).
 RTX_DEV void div2(float a1, float b1, float a2, float b2, float &q1, float &q2)
 {
+#ifdef RTX_NO_DIV2
+    q1 = a1 / b1;
+    q2 = a2 / b2;
+    return;
+#endif
     bool scaled1, scaled2, ignore;
     const F2 d = {__builtin_amdgcn_div_scalef(a1, b1, false, &ignore), __builtin_amdgcn_div_scalef(a2, b2, false, &ignore)};
     const F2 n = {__builtin_amdgcn_div_scalef(a1, b1, true, &scaled1), __builtin_amdgcn_div_scalef(a2, b2, true, &scaled2)};

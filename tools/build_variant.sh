@@ -8,7 +8,7 @@ out=$root/build_variants/$name
 mkdir -p $out
 cd $root/raytracing_amd/csrc
 for f in rtx_api.hip rtx_kernels.hip rtx_wavefront.hip rtx_bvh.cpp; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -Wno-unused-function $flags -x hip -c -o $out/${f%.*}.o $f &
+  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -Wno-unused-function $flags -x hip -c -o $out/${f%.*}.o $f &
 done
 wait
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/librtx.so $out/*.o -ldl

@@ -3,7 +3,7 @@
 # own resource report (-Rpass-analysis=kernel-resource-usage).  Usage: tools/resource_usage.sh > out.txt
 set -e
 cd "$(dirname "$0")/../raytracing_amd/csrc"
-FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -x hip -c -Rpass-analysis=kernel-resource-usage ${EXTRA_FLAGS}"
+FLAGS="-O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -x hip -c -Rpass-analysis=kernel-resource-usage ${EXTRA_FLAGS}"
 printf "%-72s %5s %5s %5s %7s %7s %8s %4s %7s\n" kernel SGPR VGPR AGPR spillS spillV scratchB occ ldsB
 for f in rtx_kernels.hip rtx_wavefront.hip rtx_api.hip; do
   /opt/rocm/bin/hipcc $FLAGS -o /dev/null $f 2>&1 | awk '
