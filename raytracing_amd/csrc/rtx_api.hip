@@ -883,6 +883,8 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
             }
         }
         if (probe) {
+            // the launch deals out work units (8 x 8 tiles or pairs of them): at most n_tiles
+            const uint32_t n_units = rtx::megakernel_units(P, c->src);
             uint32_t *cost = tiles, *order = tiles + n_tiles;
             // the tables keep the last call's contents: costs are maxima and must start from zero
             HIP_TRY(hipMemsetAsync(cost, 0, n_tiles * sizeof(uint32_t), stream));
@@ -890,7 +892,7 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
             A.sample_count = probe;
             A.tile_cost = cost;
             HIP_TRY(rtx::launch_megakernel(A, c->src, false, c->pool_limit, stream));
-            HIP_TRY(rtx::launch_tile_order(cost, order, n_tiles, stream));
+            HIP_TRY(rtx::launch_tile_order(cost, order, n_units, stream));
             P.sample_first = sample_first + probe;
             P.sample_count = sample_count - probe;
             P.accumulate = 1u;

@@ -85,6 +85,8 @@ enum : int { kSrcLds = 0, kSrcScalar = 1, kSrcBvh = 2 };
 constexpr uint32_t kFewLights = 2;
 // pool_limit caps the hand-over pool of a wave (entries; kPoolEntriesMax = whatever fits the LDS)
 hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, uint32_t pool_limit, hipStream_t stream);
+// work units of a megakernel launch: what tile_order permutes and tile_cost is indexed by
+uint32_t megakernel_units(const RenderParams &p, int src);
 // order[0..n_tiles) = the tiles by decreasing cost[] (buckets of one unit, costs above
 // kTileCostMax share the first bucket)
 constexpr uint32_t kTileCostMax = 2047u;

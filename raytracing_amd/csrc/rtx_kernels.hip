@@ -120,6 +120,10 @@ RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, flo
 #ifndef RTX_MK_DIFFUSE_BVH
 #define RTX_MK_DIFFUSE_BVH 0u
 #endif
+// 1: linear-scan scenes run k_megakernel_scan2 (two pixels per lane), 0: k_megakernel
+#ifndef RTX_MK_TWO
+#define RTX_MK_TWO 1
+#endif
 #ifndef RTX_MEGAKERNEL_ATTR
 #define RTX_MEGAKERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))  // at most 128 VGPRs: 4 waves per SIMD measured fastest for the scan and the BVH kernels alike
 #endif
@@ -373,6 +377,302 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Linear-scan scenes: two pixels per lane.
+//
+// A closest-hit scan runs with every lane busy, but only about two thirds of the hits go on to a
+// scatter (the others end their path: a light, a black surface, the depth limit), so a scatter
+// that follows every scan runs a third empty before its own branches thin it further -- and the
+// scatter is two thirds of the work.  Here a wave owns TWO 8x8 tiles side by side and a lane one
+// pixel of each: one pixel's state ("context": path, sample counters, sum) is in registers, the
+// other's is parked in LDS (6 x 16 bytes per lane, one ds_read/write_b128 each way per part).
+// Every round scans for the context that needs a scan -- swapping the two where the parked one
+// does and the current one does not -- and the scatter runs only when at least
+// RTX_MK2_SCATTER_MIN lanes have a context waiting for one (or nothing else can be done), each
+// lane bringing in whichever of its contexts waits.  A pixel's samples are still traced one after
+// the other and added in order, so the image keeps its bits.
+//
+// The hand-over of samples between lanes works as in k_megakernel, between the contexts that are
+// in registers at that moment; `job` names the owner of the sample in flight: lane (bits 0-5),
+// tile half (bit 6), pool entry (bits 7-16).
+#ifndef RTX_MK2_SCATTER_MIN
+#define RTX_MK2_SCATTER_MIN 50u
+#endif
+// Build with -DRTX_MK_DEBUG to count, per launch, the rounds of the two-pixel kernel and the lanes
+// each step served (rtx_mk_debug_read; tools/mk_debug.py).
+#ifdef RTX_MK_DEBUG
+__device__ unsigned long long g_mk_dbg[16];
+#define MK_DBG(i, n) dbg[i] += (n)
+#else
+#define MK_DBG(i, n) ((void)0)
+#endif
+enum { M_ROUNDS = 0, M_SCAN_ROUNDS, M_SCAN_LANES, M_SCATTER_ROUNDS, M_SCATTER_LANES, M_SWAP_ROUNDS, M_SWAP_LANES, M_FRESH_LANES, M_COUNT };
+constexpr uint32_t kParkVec = 6u;   // float4 per parked context
+enum : uint32_t { kPhaseEmpty = 0u,    // no sample in flight, none of its own left to start
+                  kPhaseIdle = 1u,     // no sample in flight, own samples left
+                  kPhaseScan = 2u,     // a ray whose closest hit is wanted
+                  kPhaseScatter = 3u };// hit known (hit_idx, hit_t), diffuse scatter wanted
+struct PixelContext {
+    Path p;
+    V3 sum;
+    uint32_t s, job, next, end, head;
+    int hit_idx;
+    float hit_t;
+    uint32_t phase;   // bits 0-1 phase, bit 2 tile half, bit 3 pixel inside the image
+};
+RTX_DEV void park_store(float4 *park, const PixelContext &c)
+{
+    park[0 * 256] = make_float4(c.p.o.x, c.p.o.y, c.p.o.z, c.p.T.x);
+    park[1 * 256] = make_float4(c.p.d.x, c.p.d.y, c.p.d.z, c.p.T.y);
+    park[2 * 256] = make_float4(c.p.L.x, c.p.L.y, c.p.L.z, c.p.T.z);
+    park[3 * 256] = make_float4(c.sum.x, c.sum.y, c.sum.z, c.hit_t);
+    park[4 * 256] = make_float4(__uint_as_float(c.s), __uint_as_float(c.job), __uint_as_float(c.next), __uint_as_float(c.end));
+    park[5 * 256] = make_float4(__uint_as_float(c.head), __uint_as_float(c.p.depth), __int_as_float(c.hit_idx), __uint_as_float(c.phase));
+}
+RTX_DEV PixelContext park_load(const float4 *park)
+{
+    const float4 a = park[0 * 256], b = park[1 * 256], c = park[2 * 256], d = park[3 * 256], e = park[4 * 256], f = park[5 * 256];
+    PixelContext x;
+    x.p.o = v3(a.x, a.y, a.z);
+    x.p.d = v3(b.x, b.y, b.z);
+    x.p.L = v3(c.x, c.y, c.z);
+    x.p.T = v3(a.w, b.w, c.w);
+    x.sum = v3(d.x, d.y, d.z);
+    x.hit_t = d.w;
+    x.s = __float_as_uint(e.x);
+    x.job = __float_as_uint(e.y);
+    x.next = __float_as_uint(e.z);
+    x.end = __float_as_uint(e.w);
+    x.head = __float_as_uint(f.x);
+    x.p.depth = __float_as_uint(f.y);
+    x.hit_idx = __float_as_int(f.z);
+    x.phase = __float_as_uint(f.w);
+    return x;
+}
+
+__host__ __device__ inline uint32_t scan_units_x(uint32_t width) { return (width + 15u) >> 4; }
+__host__ __device__ inline uint32_t scan_units(uint32_t width, uint32_t height) { return scan_units_x(width) * ((height + 7u) >> 3); }
+
+template <int SRC, bool STATS, bool MANY_LIGHTS, bool RECORD = false>
+__global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel_scan2(const RenderParams P)
+{
+    static_assert(SRC != kSrcBvh, "the two-pixel kernel is the linear scan's");
+    Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
+    uint32_t unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (unit >= scan_units(P.width, P.height)) return;   // the whole wave
+    if (P.tile_order) unit = P.tile_order[unit];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t unit_x = (unit % scan_units_x(P.width)) * 16u + (lane & 7u), unit_y = (unit / scan_units_x(P.width)) * 8u + (lane >> 3);
+    // LDS: [object table][parked contexts of the workgroup][the waves' pools]
+    float4 *park = rtx_smem + fixed_lds_bytes<SRC>(P) / 16u + threadIdx.x;
+    float4 *pool = rtx_smem + fixed_lds_bytes<SRC>(P) / 16u + kParkVec * 256u + (threadIdx.x >> 6) * P.pool_entries;
+    uint32_t pool_used = 0;   // wave-uniform
+
+    uint32_t rays = 0;
+    Counters<STATS> cnt;
+    cnt.clear();
+    const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
+    const uint32_t last = P.sample_first + P.sample_count;
+    auto fresh_context = [&](uint32_t half) {
+        PixelContext c;
+        c.p.o = c.p.d = c.p.T = c.p.L = v3(0.0f, 0.0f, 0.0f);
+        c.p.depth = 0;
+        c.sum = v3(0.0f, 0.0f, 0.0f);
+        const uint32_t px = unit_x + 8u * half;
+        const bool in_image = px < P.width && unit_y < P.height;
+        if (in_image && P.accumulate) {
+            const float *out = P.out_sum + 3ull * (unit_y * P.width + px);
+            c.sum = v3(out[0], out[1], out[2]);
+        }
+        c.s = 0;
+        c.job = lane | (half << 6);
+        c.next = in_image ? P.sample_first : last;   // own samples [next, end) are not started yet
+        c.end = last;                                // own samples [end, last) were handed over
+        c.head = kNoEntry;                           // entry of own sample `end`, the list's first
+        c.hit_idx = -1;
+        c.hit_t = 0.0f;
+        c.phase = (c.next < c.end ? kPhaseIdle : kPhaseEmpty) | (half << 2) | (in_image ? 8u : 0u);
+        return c;
+    };
+    PixelContext c = fresh_context(1u);
+    park_store(park, c);
+    uint32_t parked_phase = c.phase & 3u;   // what the context in LDS waits for
+    c = fresh_context(0u);
+
+    auto set_phase = [&](uint32_t ph) { c.phase = (c.phase & ~3u) | ph; };
+    auto swap_contexts = [&]() {
+        const PixelContext other = park_load(park);
+        park_store(park, c);
+        parked_phase = c.phase & 3u;
+        c = other;
+    };
+    // the sample in flight is complete: its radiance goes to its owner's sum or pool entry
+    auto finish_sample = [&]() {
+        if ((c.job & 127u) == (lane | (((c.phase >> 2) & 1u) << 6))) {
+            c.sum = c.sum + c.p.L;
+        } else {
+            float4 *e = pool + (c.job >> 7);
+            e->x = c.p.L.x;
+            e->y = c.p.L.y;
+            e->z = c.p.L.z;
+        }
+        set_phase(c.next < c.end ? kPhaseIdle : kPhaseEmpty);
+    };
+    auto scannable = [](uint32_t ph) { return ph == kPhaseIdle || ph == kPhaseScan; };
+    uint32_t dbg[M_COUNT] = {};
+    (void)dbg;
+
+    for (;;) {
+        MK_DBG(M_ROUNDS, 1u);
+        // the context that can use a scan comes into the registers
+        {
+            const bool sw = !scannable(c.phase & 3u) && scannable(parked_phase);
+#ifdef RTX_MK_DEBUG
+            const uint32_t n_sw = (uint32_t)__popcll(__ballot(sw));
+            MK_DBG(M_SWAP_ROUNDS, n_sw ? 1u : 0u);
+            MK_DBG(M_SWAP_LANES, n_sw);
+#endif
+            if (sw) swap_contexts();
+        }
+        bool fresh = false;
+        if ((c.phase & 3u) == kPhaseIdle) {
+            c.job = lane | (((c.phase >> 2) & 1u) << 6);
+            c.s = c.next++;
+            set_phase(kPhaseScan);
+            fresh = true;
+        }
+        if (pool_used < P.pool_entries) {
+            // lanes with nothing to scan in either context take over a sample of the context (among
+            // those in registers) that has the most left
+            unsigned long long idle = __ballot((c.phase & 3u) == kPhaseEmpty);
+            while (idle != 0ull && pool_used < P.pool_entries) {
+                const uint32_t key = c.end - c.next;
+                const uint32_t most = wave_max(key);
+                if (most == 0u) break;
+                const int giver = __builtin_ctzll(__ballot(key == most));
+                const int taker = __builtin_ctzll(idle);
+                const uint32_t taken = (uint32_t)__builtin_amdgcn_readlane((int)c.end, giver) - 1u;
+                const uint32_t giver_half = ((uint32_t)__builtin_amdgcn_readlane((int)c.phase, giver) >> 2) & 1u;
+                if ((int)lane == giver) {
+                    pool[pool_used].w = __uint_as_float(c.head);
+                    c.head = pool_used;
+                    c.end = taken;
+                    if ((c.phase & 3u) == kPhaseIdle && c.next >= c.end) set_phase(kPhaseEmpty);
+                }
+                if ((int)lane == taker) {
+                    c.job = (uint32_t)giver | (giver_half << 6) | (pool_used << 7);
+                    c.s = taken;
+                    set_phase(kPhaseScan);
+                    fresh = true;
+                }
+                pool_used += 1u;
+                idle &= idle - 1ull;
+            }
+        }
+        if (__ballot((c.phase & 3u) != kPhaseEmpty || parked_phase != kPhaseEmpty) == 0ull) break;
+        const uint32_t px = unit_x - (lane & 7u) + (c.job & 7u) + 8u * ((c.job >> 6) & 1u);
+        const uint32_t py = unit_y - (lane >> 3) + ((c.job & 63u) >> 3);
+        const uint32_t pixel = py * P.width + px;
+        if (fresh) {
+            uint4 w = draw_block(P, pixel, c.s, 0u);
+            camera_ray(P, px, P.height - 1u - py, u24(w.x), u24(w.y), c.p.o, c.p.d);
+            c.p.T = v3(1.0f, 1.0f, 1.0f);
+            c.p.L = v3(0.0f, 0.0f, 0.0f);
+            c.p.depth = 0;
+            cnt.template add<C_SAMPLES>();
+        }
+        const bool scanning = (c.phase & 3u) == kPhaseScan;
+#ifdef RTX_MK_DEBUG
+        {
+            const uint32_t n_sc = (uint32_t)__popcll(__ballot(scanning));
+            MK_DBG(M_SCAN_ROUNDS, n_sc ? 1u : 0u);
+            MK_DBG(M_SCAN_LANES, n_sc);
+            MK_DBG(M_FRESH_LANES, (uint32_t)__popcll(__ballot(fresh)));
+        }
+#endif
+        if (scanning) {
+            cnt.template add<C_RAYS>();
+            if constexpr (RECORD) rays += 1u;
+            float t;
+            const int idx = closest_hit_scan<true>(tab, c.p.o, c.p.d, t);
+            bool done;
+            if (idx < 0) {
+                c.p.L = c.p.L + cmul(c.p.T, bg);
+                done = true;
+            } else {
+                if constexpr (STATS) {
+                    int kind = __float_as_int(tab.geom[3 * idx + 1].w) & 0xff;
+                    cnt.template add<C_HIT_PLANE>(kind == kPlane);
+                    cnt.template add<C_HIT_ELLIPSOID>(kind == kEllipsoid);
+                    cnt.template add<C_HIT_BOX>(kind == kBox);
+                }
+                // emission, depth cut and the cheap materials at once; the diffuse scatter waits
+                done = surface_emission(P, tab, c.p, idx) || black_surface_ends(P, tab, c.p, idx);
+                if (!done) {
+                    const int material = __float_as_int(tab.mat[3 * idx + 0].w);
+                    if (material == kDiffuse) {
+                        c.hit_idx = idx;
+                        c.hit_t = t;
+                        set_phase(kPhaseScatter);
+                    } else {
+                        done = bounce<STATS, MANY_LIGHTS>(P, tab, c.p, idx, t, material, pixel, c.s, cnt);
+                    }
+                }
+            }
+            if (done) finish_sample();
+        }
+        // the scatter: when enough lanes have a context that waits for it, or no lane could scan next
+        const uint32_t n_wait = (uint32_t)__popcll(__ballot((c.phase & 3u) == kPhaseScatter || parked_phase == kPhaseScatter));
+        const bool can_scan = __ballot(scannable(c.phase & 3u) || scannable(parked_phase)) != 0ull;
+        if (n_wait >= RTX_MK2_SCATTER_MIN || (n_wait != 0u && !can_scan)) {
+            {
+                const bool sw = (c.phase & 3u) != kPhaseScatter && parked_phase == kPhaseScatter;
+#ifdef RTX_MK_DEBUG
+                const uint32_t n_sw = (uint32_t)__popcll(__ballot(sw));
+                MK_DBG(M_SWAP_ROUNDS, n_sw ? 1u : 0u);
+                MK_DBG(M_SWAP_LANES, n_sw);
+#endif
+                if (sw) swap_contexts();
+            }
+            MK_DBG(M_SCATTER_ROUNDS, 1u);
+            MK_DBG(M_SCATTER_LANES, (uint32_t)__popcll(__ballot((c.phase & 3u) == kPhaseScatter)));
+            if ((c.phase & 3u) == kPhaseScatter) {
+                const uint32_t qx = unit_x - (lane & 7u) + (c.job & 7u) + 8u * ((c.job >> 6) & 1u);
+                const uint32_t qy = unit_y - (lane >> 3) + ((c.job & 63u) >> 3);
+                set_phase(kPhaseScan);
+                if (bounce<STATS, MANY_LIGHTS>(P, tab, c.p, c.hit_idx, c.hit_t, kDiffuse, qy * P.width + qx, c.s, cnt)) finish_sample();
+            }
+        }
+    }
+    // both pixels of the lane: own samples, then the handed-over ones in sample order
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (c.phase & 8u) {
+            V3 total = c.sum;
+            for (uint32_t e = c.head; e != kNoEntry;) {   // samples end .. last-1 in this order
+                const float4 v = pool[e];
+                total = total + v3(v.x, v.y, v.z);
+                e = __float_as_uint(v.w);
+            }
+            float *out = P.out_sum + 3ull * (unit_y * P.width + unit_x + 8u * ((c.phase >> 2) & 1u));
+            out[0] = total.x;
+            out[1] = total.y;
+            out[2] = total.z;
+        }
+        if (k == 0) c = park_load(park);
+    }
+    if constexpr (RECORD) atomicMax(&P.tile_cost[unit], rays);
+    if constexpr (STATS) {
+#pragma unroll
+        for (int i = 0; i < C_COUNT; ++i)
+            if (cnt.v[i]) atomicAdd(&P.stats[i], (unsigned long long)cnt.v[i]);
+    }
+#ifdef RTX_MK_DEBUG
+    if (lane == 0u)
+        for (int i = 0; i < M_COUNT; ++i) atomicAdd(&g_mk_dbg[i], (unsigned long long)dbg[i]);
+#endif
+}
+
 template <int SRC>
 __global__ void __launch_bounds__(256) k_primary(const RenderParams P, const PrimaryParams out)
 {
@@ -470,19 +770,54 @@ static void launch_megakernel_src(const RenderParams &p, bool stats, dim3 grid, 
         else hipLaunchKernelGGL((k_megakernel<SRC, false, false>), grid, block, lds, stream, p);
     }
 }
+template <int SRC>
+static void launch_megakernel_scan2(const RenderParams &p, bool stats, dim3 grid, size_t lds, hipStream_t stream)
+{
+    const dim3 block(256);
+    const bool many = p.n_lights > kFewLights;
+    if (stats) {
+        if (many) hipLaunchKernelGGL((k_megakernel_scan2<SRC, true, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((k_megakernel_scan2<SRC, true, false>), grid, block, lds, stream, p);
+    } else if (p.tile_cost) {
+        if (many) hipLaunchKernelGGL((k_megakernel_scan2<SRC, false, true, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((k_megakernel_scan2<SRC, false, false, true>), grid, block, lds, stream, p);
+    } else {
+        if (many) hipLaunchKernelGGL((k_megakernel_scan2<SRC, false, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((k_megakernel_scan2<SRC, false, false>), grid, block, lds, stream, p);
+    }
+}
+
+// The two-pixel kernel parks one context per lane in LDS (24 KB per workgroup): used when that and
+// the object table fit a workgroup's 40 KB share of the CU, so that four workgroups still do.
+static bool two_pixels_per_lane(const RenderParams &p, int src)
+{
+    return RTX_MK_TWO && src != kSrcBvh && fixed_lds_bytes(p, src) + kParkVec * 256u * sizeof(float4) <= 40u * 1024u;
+}
+// work units a megakernel launch deals out to its waves (and the tile cost / order tables index):
+// 8x8 tiles, or pairs of them (16x8 pixels) for the two-pixel kernel
+uint32_t megakernel_units(const RenderParams &p, int src)
+{
+    if (two_pixels_per_lane(p, src)) return scan_units(p.width, p.height);
+    return ((p.width + 7u) / 8u) * ((p.height + 7u) / 8u);
+}
 
 hipError_t launch_megakernel(const RenderParams &p0, int src, bool stats, uint32_t pool_limit, hipStream_t stream)
 {
     RenderParams p = p0;
-    const dim3 grid = tile_grid(p);
+    const bool two = two_pixels_per_lane(p, src);
+    const dim3 grid((megakernel_units(p, src) + 3u) / 4u);
     // four workgroups share a CU's 160 KB of LDS: what the table (scan) or the traversal
-    // stacks (BVH) leave of 40 KB goes to the four waves' hand-over pools
-    const size_t fixed = fixed_lds_bytes(p, src);
+    // stacks (BVH), and the parked pixel contexts of the two-pixel kernel, leave of 40 KB goes to
+    // the four waves' hand-over pools
+    const size_t fixed = fixed_lds_bytes(p, src) + (two ? kParkVec * 256u * sizeof(float4) : 0u);
     const size_t budget = 40u * 1024u;
     p.pool_entries = fixed < budget ? (uint32_t)std::min<size_t>(kPoolEntriesMax, (budget - fixed) / (4u * sizeof(float4))) : 0u;
     p.pool_entries = std::min(p.pool_entries, pool_limit);
     const size_t lds = fixed + (size_t)p.pool_entries * 4u * sizeof(float4);
-    if (src == kSrcLds) launch_megakernel_src<kSrcLds>(p, stats, grid, lds, stream);
+    if (two) {
+        if (src == kSrcLds) launch_megakernel_scan2<kSrcLds>(p, stats, grid, lds, stream);
+        else launch_megakernel_scan2<kSrcScalar>(p, stats, grid, lds, stream);
+    } else if (src == kSrcLds) launch_megakernel_src<kSrcLds>(p, stats, grid, lds, stream);
     else if (src == kSrcScalar) launch_megakernel_src<kSrcScalar>(p, stats, grid, lds, stream);
     else launch_megakernel_src<kSrcBvh>(p, stats, grid, lds, stream);
     return hipGetLastError();
@@ -523,3 +858,13 @@ hipError_t launch_tonemap(const float *sum, uint64_t n, float divisor, uint8_t *
 }
 
 }  // namespace rtx
+
+#ifdef RTX_MK_DEBUG
+extern "C" int rtx_mk_debug_read(unsigned long long *out, int reset)
+{
+    unsigned long long zero[16] = {};
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtx::g_mk_dbg), sizeof(zero)) != hipSuccess) return -1;
+    if (reset && hipMemcpyToSymbol(HIP_SYMBOL(rtx::g_mk_dbg), zero, sizeof(zero)) != hipSuccess) return -1;
+    return rtx::M_COUNT;
+}
+#endif

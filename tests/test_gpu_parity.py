@@ -298,6 +298,28 @@ def test_bvh_on_the_reference_scene_and_auto_selection(oracle):
         assert e.value.code == _abi.RTX_ERR_UNSUPPORTED
 
 
+def test_linear_scan_with_small_and_large_object_tables(oracle):
+    """The scan megakernel keeps two pixels per lane, one of them parked in LDS, when the object
+    table leaves room for that (100 objects) and one pixel per lane when it does not (400 objects
+    fill the workgroup's LDS share); cost-ordered dispatch on top (64 spp, 8192+ tiles)."""
+    for n_prims, w, h, spp in ((100, 57, 33, 3), (400, 57, 33, 2), (100, 1021, 771, 64)):
+        sc = synthetic_scene(n_prims=n_prims, seed=17, width=w, height=h, n_samples=spp, ray_depth=4, n_lights=2)
+        if spp < 10:
+            want = oracle.render(sc, seed=9, order=oracle.ORDER_FORWARD)
+        for accel in (_abi.ACCEL_BRUTE_LDS, _abi.ACCEL_BRUTE_SCALAR):
+            with Renderer(seed=9, accel=accel) as r:
+                got = r.render(sc)
+            if spp < 10:
+                assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), (n_prims, accel)
+            elif accel == _abi.ACCEL_BRUTE_LDS:
+                first = got
+            else:
+                assert np.array_equal(first.view(np.uint32), got.view(np.uint32))
+    # the large frame against the BVH kernels (one pixel per lane, another launch shape)
+    with Renderer(seed=9, accel=_abi.ACCEL_BVH) as r:
+        assert np.array_equal(first.view(np.uint32), r.render(sc).view(np.uint32))
+
+
 def test_bvh_ties_go_to_the_lowest_index(oracle):
     """Coincident objects: the scan keeps the first minimum; the BVH must too."""
     from raytracing_amd import Prim
