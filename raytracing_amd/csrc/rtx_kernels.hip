@@ -787,11 +787,13 @@ static void launch_megakernel_scan2(const RenderParams &p, bool stats, dim3 grid
     }
 }
 
-// The two-pixel kernel parks one context per lane in LDS (24 KB per workgroup): used when that and
-// the object table fit a workgroup's 40 KB share of the CU, so that four workgroups still do.
+// The two-pixel kernel parks one context per lane in LDS (24 KB per workgroup): used for the scenes it
+// pays on (paths_end_at_lights, set at upload) when that and the object table fit a workgroup's 40 KB
+// share of the CU, so that four workgroups still do.
 static bool two_pixels_per_lane(const RenderParams &p, int src)
 {
-    return RTX_MK_TWO && src != kSrcBvh && fixed_lds_bytes(p, src) + kParkVec * 256u * sizeof(float4) <= 40u * 1024u;
+    return RTX_MK_TWO && src != kSrcBvh && p.paths_end_at_lights != 0u &&
+           fixed_lds_bytes(p, src) + kParkVec * 256u * sizeof(float4) <= 40u * 1024u;
 }
 // work units a megakernel launch deals out to its waves (and the tile cost / order tables index):
 // 8x8 tiles, or pairs of them (16x8 pixels) for the two-pixel kernel

@@ -299,9 +299,9 @@ def test_bvh_on_the_reference_scene_and_auto_selection(oracle):
 
 
 def test_linear_scan_with_small_and_large_object_tables(oracle):
-    """The scan megakernel keeps two pixels per lane, one of them parked in LDS, when the object
-    table leaves room for that (100 objects) and one pixel per lane when it does not (400 objects
-    fill the workgroup's LDS share); cost-ordered dispatch on top (64 spp, 8192+ tiles)."""
+    """The linear scan with object tables of 100 and 400 entries, staged in LDS or read through
+    scalar loads (the 400-entry table fills the workgroup's LDS share: no hand-over pool), and
+    with the cost-ordered dispatch on top (64 spp, 8192+ tiles), against the oracle and the BVH."""
     for n_prims, w, h, spp in ((100, 57, 33, 3), (400, 57, 33, 2), (100, 1021, 771, 64)):
         sc = synthetic_scene(n_prims=n_prims, seed=17, width=w, height=h, n_samples=spp, ray_depth=4, n_lights=2)
         if spp < 10:
