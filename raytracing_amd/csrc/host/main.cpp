@@ -4,6 +4,7 @@
 // benchmark configurations can reuse one scene file:
 //   --size W H   --spp N   --depth N   --seed N   --mode megakernel|wavefront
 //   --gpus N              split the samples over GPUs 0..N-1 of the node (sums added on the GPUs)
+//   --devices a,b,...     the same over the listed HIP ordinals (an ordinal may repeat)
 //   --reduce p2p|rccl     how: peer-access slice reduce (default) or RCCL all-reduce
 // Output stage:
 //   --device-tonemap      tone map and quantise on the GPU; only bytes come back
@@ -30,6 +31,7 @@ int main(int argc, char **argv)
     long width = -1, height = -1, spp = -1, depth = -1, chunk = -1, stop_after = -1;
     bool device_tonemap = false;
     std::string checkpoint;
+    std::vector<int32_t> devices;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto need = [&](int k) {
@@ -41,6 +43,17 @@ int main(int argc, char **argv)
         else if (a == "--seed") { need(1); opts.seed = std::strtoull(argv[++i], nullptr, 10); }
         else if (a == "--mode") { need(1); opts.mode = std::string(argv[++i]) == "wavefront" ? RTX_MODE_WAVEFRONT : RTX_MODE_MEGAKERNEL; }
         else if (a == "--gpus") { need(1); opts.n_devices = (int32_t)std::atol(argv[++i]); }
+        else if (a == "--devices") {
+            need(1);
+            devices.clear();
+            for (const char *q = argv[++i]; *q;) {
+                char *end = nullptr;
+                devices.push_back((int32_t)std::strtol(q, &end, 10));
+                if (end == q) { std::fprintf(stderr, "--devices wants a comma-separated list of ordinals\n"); return 2; }
+                q = *end == ',' ? end + 1 : end;
+            }
+            opts.n_devices = (int32_t)devices.size();
+        }
         else if (a == "--reduce") { need(1); opts.reduce = std::string(argv[++i]) == "rccl" ? RTX_REDUCE_RCCL : RTX_REDUCE_P2P; }
         else if (a == "--chunk") { need(1); chunk = std::atol(argv[++i]); }
         else if (a == "--stop-after") { need(1); stop_after = std::atol(argv[++i]); }
@@ -65,6 +78,7 @@ int main(int argc, char **argv)
     if (spp >= 0) hs.scene.n_samples = (uint32_t)spp;
     if (depth >= 0) hs.scene.ray_depth = (uint32_t)depth;
 
+    if (!devices.empty()) opts.devices = devices.data();
     rtx_ctx *ctx = nullptr;
     if (rtx_create(&ctx, &opts) != RTX_OK) {
         std::fprintf(stderr, "rtx_create: %s\n", rtx_last_error());

@@ -298,6 +298,44 @@ def test_bvh_on_the_reference_scene_and_auto_selection(oracle):
         assert e.value.code == _abi.RTX_ERR_UNSUPPORTED
 
 
+def test_two_pixels_per_lane_kernel_variants(oracle):
+    """Small all-diffuse scenes whose lights are black run the scan kernel that keeps two pixels
+    per lane.  Its variants -- few and many lights, LDS and scalar table, event counters, a
+    continued sum, a ragged image one tile wide -- against the oracle, bits and counters."""
+    import torch
+    from raytracing_amd import Prim, normalize_quaternion
+    base = reference_scene(width=77, height=43, n_samples=5)
+    many = base.replace(prims=base.prims + [
+        Prim(_abi.BOX, (0.5, 0.1, 0.5), position=(-3, 4.5, 1), emission=(3, 2, 1)),
+        Prim(_abi.ELLIPSOID, (0.6, 0.3, 0.5), position=(3, 3.5, 1), rotation=normalize_quaternion(0.3, 0.1, 0.2, 0.9),
+             emission=(1, 2, 3)),
+        Prim(_abi.BOX, (0.4, 0.4, 0.4), position=(0, -4, 3), rotation=normalize_quaternion(0.1, 0.5, 0.0, 0.8),
+             emission=(2, 2, 2))])
+    for sc in (base, many, base.replace(width=5, height=19)):
+        want, wstats = oracle.render(sc, seed=14, order=oracle.ORDER_FORWARD, want_stats=True)
+        for accel in (_abi.ACCEL_BRUTE_LDS, _abi.ACCEL_BRUTE_SCALAR):
+            with Renderer(seed=14, accel=accel) as r:
+                got = r.render(sc)
+            assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), (len(sc.prims), accel)
+        with Renderer(seed=14, accel=_abi.ACCEL_BRUTE_LDS, collect_stats=True) as r:
+            got = r.render(sc)
+            st = r.stats()
+        st.pop("bvh_node_tests")
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32)) and st == wstats
+    # sums continued over two calls, the second starting in the middle of the sample range
+    n = many.width * many.height * 3
+    with Renderer(seed=14) as r:
+        r.set_scene(many)
+        buf = torch.empty(n, dtype=torch.float32, device="cuda")
+        stream = torch.cuda.current_stream().cuda_stream
+        r.render_samples(0, 2, buf.data_ptr(), stream)
+        r.accumulate_samples(2, 3, buf.data_ptr(), stream)
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy().reshape(many.height, many.width, 3)
+    want = oracle.render(many, seed=14, order=oracle.ORDER_FORWARD, output_sum=True)
+    assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+
+
 def test_linear_scan_with_small_and_large_object_tables(oracle):
     """The linear scan with object tables of 100 and 400 entries, staged in LDS or read through
     scalar loads (the 400-entry table fills the workgroup's LDS share: no hand-over pool), and

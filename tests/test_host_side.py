@@ -226,6 +226,31 @@ def test_cli_renders_the_sample_scene(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_cli_splits_the_samples_over_a_device_list(tmp_path):
+    """rtx_cli --devices: the reference's driver with the sample loop split inside the library
+    (this box has one GPU, so it is named three times); the file equals the Python binding's
+    render of the same split, and differs from the unsplit one by rounding only."""
+    from raytracing_amd.renderer import Renderer
+    scene_path = tmp_path / "scene.txt"
+    scene_path.write_text(SAMPLE)
+    cli = os.path.join(ROOT, "raytracing_amd", "rtx_cli")
+    common = ["--size", "64", "48", "--spp", "7", "--seed", "3"]
+    split, whole = tmp_path / "split.ppm", tmp_path / "whole.ppm"
+    subprocess.check_call([cli, str(scene_path), str(split), "--devices", "0,0,0"] + common)
+    subprocess.check_call([cli, str(scene_path), str(whole), "--gpus", "1"] + common)
+    header = b"P6\n64 48\n255\n"
+    a = np.frombuffer(split.read_bytes()[len(header):], dtype=np.uint8)
+    b = np.frombuffer(whole.read_bytes()[len(header):], dtype=np.uint8)
+    sc = host.parse_scene_text(SAMPLE).replace(width=64, height=48, n_samples=7)
+    with Renderer(seed=3, devices=[0, 0, 0]) as r:
+        want = host.to_bytes(host.color_correction(r.render(sc))).reshape(-1)
+    assert np.array_equal(a, want)
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    res = subprocess.run([cli, str(scene_path), str(split), "--devices", "0,77"] + common, capture_output=True, text=True)
+    assert res.returncode == 1 and "out of range" in res.stderr
+
+
+@pytest.mark.gpu
 def test_cli_checkpoint_resume_and_device_tonemap(tmp_path):
     """A render that is stopped, resumed from its checkpoint and cut into uneven steps writes
     the same file as the one-shot render; the device tone map differs from the host's by at
