@@ -127,6 +127,16 @@ RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, flo
 #ifndef RTX_MEGAKERNEL_ATTR
 #define RTX_MEGAKERNEL_ATTR __attribute__((amdgpu_waves_per_eu(4)))  // at most 128 VGPRs: 4 waves per SIMD measured fastest for the scan and the BVH kernels alike
 #endif
+// Build with -DRTX_MK_DEBUG to count, per launch, the rounds of the megakernels and the lanes each
+// step served (rtx_mk_debug_read; tools/mk_debug.py).
+#ifdef RTX_MK_DEBUG
+__device__ unsigned long long g_mk_dbg[16];
+#define MK_DBG(i, n) dbg[i] += (n)
+#else
+#define MK_DBG(i, n) ((void)0)
+#endif
+enum { M_ROUNDS = 0, M_SCAN_ROUNDS, M_SCAN_LANES, M_SCATTER_ROUNDS, M_SCATTER_LANES, M_SWAP_ROUNDS, M_SWAP_LANES, M_FRESH_LANES,
+       M_NODE_ROUNDS, M_NODE_LANES, M_LEAF_ROUNDS, M_LEAF_LANES, M_START_ROUNDS, M_START_LANES, M_COUNT };
 // largest value of `v` over the wave's 64 lanes (every lane must be active)
 RTX_DEV uint32_t wave_max(uint32_t v)
 {
@@ -200,7 +210,10 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
         }
         active = false;
     };
+    uint32_t dbg[M_COUNT] = {};
+    (void)dbg;
     for (;;) {
+        MK_DBG(M_ROUNDS, 1u);
         const uint32_t lane = threadIdx.x & 63u;
         bool fresh = false;
         if (!active && next < end) {
@@ -267,6 +280,13 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
             const float ray_length = len(p.d);
             const bool starting = need_hit && !trav;
             const bool all_plain = __ballot(starting && !plain) == 0ull;
+#ifdef RTX_MK_DEBUG
+            {
+                const uint32_t n_st = (uint32_t)__popcll(__ballot(starting));
+                MK_DBG(M_START_ROUNDS, n_st ? 1u : 0u);
+                MK_DBG(M_START_LANES, n_st);
+            }
+#endif
             if (starting) {
                 cnt.template add<C_RAYS>();
                 if constexpr (RECORD) rays += 1u;
@@ -290,9 +310,14 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
                 // serves enough lanes, or nothing else is left to do
                 if (n_node * RTX_MK_LEAF_COST >= n_leaf) {
 #pragma unroll
-                    for (int k = 0; k < RTX_MK_NODE_BATCH; ++k)
+                    for (int k = 0; k < RTX_MK_NODE_BATCH; ++k) {
+                        MK_DBG(M_NODE_ROUNDS, 1u);
+                        MK_DBG(M_NODE_LANES, (uint32_t)__popcll(__ballot(cur >= 0)));
                         if (cur >= 0) bvh_node_step<STATS, 256>(P.bvh, R, best_t, cur, sp, stack, cnt);
+                    }
                 } else {
+                    MK_DBG(M_LEAF_ROUNDS, 1u);
+                    MK_DBG(M_LEAF_LANES, n_leaf);
                     const bool leaves_plain = P.bvh.leaves_identity != 0u && __ballot(at_leaf && !plain) == 0ull;
                     if (at_leaf) {
                         bvh_try_object<STATS>(tab, ~cur, p.o, p.d, ray_length, best, best_t, cnt, leaves_plain);
@@ -312,6 +337,13 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
                 t = best_t;
             }
         }
+#ifdef RTX_MK_DEBUG
+        {
+            const uint32_t n_hk = (uint32_t)__popcll(__ballot(hit_known));
+            MK_DBG(M_SCATTER_ROUNDS, n_hk ? 1u : 0u);
+            MK_DBG(M_SCATTER_LANES, n_hk);
+        }
+#endif
         if (hit_known) {
             bool done;
             if (idx < 0) {
@@ -375,6 +407,10 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
         for (int i = 0; i < C_COUNT; ++i)
             if (cnt.v[i]) atomicAdd(&P.stats[i], (unsigned long long)cnt.v[i]);
     }
+#ifdef RTX_MK_DEBUG
+    if ((threadIdx.x & 63u) == 0u)
+        for (int i = 0; i < M_COUNT; ++i) atomicAdd(&g_mk_dbg[i], (unsigned long long)dbg[i]);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -398,15 +434,6 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
 #ifndef RTX_MK2_SCATTER_MIN
 #define RTX_MK2_SCATTER_MIN 50u
 #endif
-// Build with -DRTX_MK_DEBUG to count, per launch, the rounds of the two-pixel kernel and the lanes
-// each step served (rtx_mk_debug_read; tools/mk_debug.py).
-#ifdef RTX_MK_DEBUG
-__device__ unsigned long long g_mk_dbg[16];
-#define MK_DBG(i, n) dbg[i] += (n)
-#else
-#define MK_DBG(i, n) ((void)0)
-#endif
-enum { M_ROUNDS = 0, M_SCAN_ROUNDS, M_SCAN_LANES, M_SCATTER_ROUNDS, M_SCATTER_LANES, M_SWAP_ROUNDS, M_SWAP_LANES, M_FRESH_LANES, M_COUNT };
 constexpr uint32_t kParkVec = 6u;   // float4 per parked context
 enum : uint32_t { kPhaseEmpty = 0u,    // no sample in flight, none of its own left to start
                   kPhaseIdle = 1u,     // no sample in flight, own samples left

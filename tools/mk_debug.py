@@ -9,7 +9,8 @@ import torch
 from bench import build_workload
 from raytracing_amd.renderer import Renderer, load_library
 
-names = ["rounds", "scan_rounds", "scan_lanes", "scatter_rounds", "scatter_lanes", "swap_rounds", "swap_lanes", "fresh_lanes"]
+names = ["rounds", "scan_rounds", "scan_lanes", "scatter_rounds", "scatter_lanes", "swap_rounds", "swap_lanes", "fresh_lanes",
+         "node_rounds", "node_lanes", "leaf_rounds", "leaf_lanes", "start_rounds", "start_lanes"]
 sc, _ = build_workload(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 32)
 lib = load_library()
 buf = torch.zeros(sc.width * sc.height * 3, dtype=torch.float32, device="cuda")
@@ -22,6 +23,13 @@ with Renderer(seed=1) as r:
     lib.rtx_mk_debug_read(out, 1)
 v = dict(zip(names, list(out)))
 print(v)
+if v["node_rounds"]:
+    print("BVH megakernel: outer rounds %d; traversal starts in %.2f of them with %.1f lanes; node steps %.1f per round with %.1f lanes; "
+          "object tests %.2f per round with %.1f lanes; scatter in %.2f of the rounds with %.1f lanes" % (
+              v["rounds"], v["start_rounds"] / v["rounds"], v["start_lanes"] / max(1, v["start_rounds"]), v["node_rounds"] / v["rounds"],
+              v["node_lanes"] / v["node_rounds"], v["leaf_rounds"] / v["rounds"], v["leaf_lanes"] / max(1, v["leaf_rounds"]),
+              v["scatter_rounds"] / v["rounds"], v["scatter_lanes"] / max(1, v["scatter_rounds"])))
+    sys.exit(0)
 print("rounds %d: scan in %.2f of them with %.1f lanes; scatter in %.2f with %.1f lanes; swaps in %.2f per round with %.1f lanes; fresh %.1f per round" % (
     v["rounds"], v["scan_rounds"] / v["rounds"], v["scan_lanes"] / max(1, v["scan_rounds"]), v["scatter_rounds"] / v["rounds"],
     v["scatter_lanes"] / max(1, v["scatter_rounds"]), v["swap_rounds"] / v["rounds"], v["swap_lanes"] / max(1, v["swap_rounds"]),
