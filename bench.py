@@ -197,8 +197,21 @@ def profile_files(workload, mode):
         return None
     with open(files[-1]) as f:
         d = json.load(f)
-    return {"source": os.path.relpath(files[-1], ROOT), "thread_active_fraction": d.get("thread_active_fraction"),
-            "hbm_bytes_per_step": d.get("hbm_bytes_per_launch")}
+    out = {"source": os.path.relpath(files[-1], ROOT), "thread_active_fraction": d.get("thread_active_fraction"),
+           "hbm_bytes_per_step": d.get("hbm_bytes_per_launch"), "valu_instructions_per_step": d.get("SQ_INSTS_VALU")}
+    # registers and occupancy of the step's dominant kernel from the compiler's resource report
+    res = os.path.join(os.path.dirname(files[-1]), "resource_usage.txt")
+    want = {("c2", "megakernel"): "k_megakernel_scan2<0, false, false, false>", ("c4", "megakernel"): "k_megakernel_scan2<0, false, false, false>",
+            ("c3", "megakernel"): "k_megakernel<2, false, true, false>", ("c5", "megakernel"): "k_megakernel<2, false, false, false>",
+            ("c2", "wavefront"): "k_wavefront<0, false, false, WfShapeT<512u, 16u, true>", ("c3", "wavefront"): "k_wavefront<2, false, true, WfShapeT<64u, 4u, false>",
+            ("c5", "wavefront"): "k_wavefront<2, false, false, WfShapeT<64u, 2u, true>"}.get((workload, mode))
+    if want and os.path.exists(res):
+        for line in open(res):
+            if line.startswith(want):
+                f = line[72:].split()
+                out["kernel"] = want + ">" if want.count("<") > want.count(">") else want
+                out["vgprs"], out["spilled_vgprs"], out["waves_per_simd"] = int(f[1]), int(f[4]), int(f[6])
+    return out
 
 
 def main():
@@ -277,7 +290,8 @@ def main():
                                           if args.mode == "megakernel" else "k_wavefront"),
                                "kernel_ms": head["kernel_ms"], "algorithmic_flops_per_launch": head["algorithmic_flops_per_launch"],
                                "flops_per_sample": head["flops_per_sample"], "rays_per_sample": head["rays_per_sample"],
-                               "events_counted_on_spp": head["events_counted_on_spp"]}
+                               "events_counted_on_spp": head["events_counted_on_spp"],
+                               "counters": profile_files(name, args.mode) if world == 1 else None}
         if extra:
             out["workloads"] = extra
             out["c4_single_gpu"] = {k: extra["c4_single_gpu"][k] for k in ("ms_per_step", "msamples_per_s", "frac", "mrays_per_s")
