@@ -1,12 +1,15 @@
-// rtx_kernels.hip -- megakernel path tracer and the deterministic primary pass (gfx950).
+// rtx_kernels.hip -- megakernel path tracers and the deterministic primary pass (gfx950).
 //
 // Work decomposition (replaces the serial loop nest of src/main.rs:13-31):
-//   * one lane per pixel; a wave64 owns an 8x8 pixel tile, a 256-thread workgroup four tiles;
+//   * one lane per pixel; a wave64 owns an 8x8 pixel tile, a 256-thread workgroup four tiles
+//     (k_megakernel); for small all-diffuse scenes with black lights a lane owns a pixel of each
+//     of two tiles, one of them parked in LDS (k_megakernel_scan2);
 //   * the sample loop (main.rs:14) and the bounce recursion (trace.rs:11-71, one child per
-//     call, so a loop) are flattened into ONE loop per lane whose iteration is a path
-//     segment: closest hit, then scatter.  A lane whose path ends starts its next sample in
-//     the same iteration, so every lane of the wave stays busy until its pixel is finished
-//     and the closest-hit scan -- the dominant cost -- always runs with a full exec mask;
+//     call, so a loop) are flattened into ONE loop per lane whose round is a path segment:
+//     closest hit, then scatter.  A lane whose path ends starts its next sample in the same
+//     round, so the closest-hit scan -- a third of the work -- runs with a full exec mask; in
+//     BVH scenes a lane's traversal can pause while other lanes scatter and go on in the next
+//     round (k_megakernel, kSrcBvh);
 //   * the object index of the scan is wave-uniform: table reads are LDS broadcasts
 //     (kSrcLds: table staged once per workgroup) or scalar loads (kSrcScalar);
 //   * each lane keeps its pixel's radiance sum in registers and stores 12 bytes once.
