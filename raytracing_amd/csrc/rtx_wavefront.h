@@ -5,8 +5,9 @@
 namespace rtx {
 
 // Path state: one 64-byte record per pixel a workgroup owns, in LDS when the workgroup's
-// queues, records and object table fit there (wavefront_state_in_lds), else in device memory
-// at slot = workgroup * 4096 + workgroup-local pixel number, a whole cache line per path:
+// queues, records and object table or traversal stacks fit there (wavefront_state_in_lds), else in
+// device memory at slot = workgroup * (pixels per workgroup) + workgroup-local pixel number, a whole
+// cache line per path:
 //   rec[4*slot+0] = ray origin xyz      | distance of the current segment's closest hit
 //   rec[4*slot+1] = ray direction xyz   | object index of that hit (int bits)
 //   rec[4*slot+2] = throughput xyz      | depth (int bits)

@@ -9,17 +9,14 @@
 // image is bit-identical to the megakernel's.
 //
 // Path state is one 64-byte record per pixel (rtx_wavefront.h), indexed by the workgroup-local
-// pixel number.  Two layouts of the workgroup (WfShape):
-//   * LDS state: 512 threads own 16 tiles (1024 pixels); the records (64 KB) sit next to the
-//     queues in LDS, two workgroups per CU.  With the state in HBM the kernel ran at the memory
-//     roof (about 400 bytes of traffic per path segment; the compacted queues hand the paths
-//     out in any order, so every stage re-reads and re-writes scattered records), while its
-//     instruction count is a fifth below the megakernel's.  Used for the linear scan (the BVH
-//     needs the LDS for its traversal stacks); an object table that does not fit beside the
-//     records is read from device memory through scalar loads instead.
-//   * HBM state: 512 threads own 64 tiles (4096 pixels), records in device memory at
-//     workgroup * 4096 + local, a whole cache line per access (a structure-of-arrays layout
-//     measured 2 KB of traffic per path segment).
+// pixel number, in LDS or in device memory; the shapes of a workgroup are listed at WfShapeT below.
+// With the state in device memory and 512-thread workgroups the linear-scan kernel ran at the memory
+// roof (about 400 bytes of traffic per path segment; the compacted queues hand the paths out in any
+// order, so every stage re-reads and re-writes scattered records), while its instruction count is a
+// fifth below the megakernel's: the linear scan keeps its records in LDS (an object table that does
+// not fit beside them is read from device memory through scalar loads instead); BVH scenes do so
+// when the traversal stacks leave room, else a whole cache line per record access (a
+// structure-of-arrays layout measured 2 KB of traffic per path segment).
 // Only the radiance sum (the output buffer) is indexed by pixel.  Queues hold 16-bit local
 // numbers.  One iteration of the in-kernel loop advances every live path of the workgroup by
 // one segment:
