@@ -7,7 +7,8 @@ and a summary; exit status 1 if anything differed.
 Environment: SWEEP_EXTREME=1 (or a comma-separated list of FEATURES) adds inputs only the C ABI
 lets through; SWEEP_BIG=k multiplies image edges and sample counts by k; SWEEP_OPTIONS=1 checks
 the other inputs of a render instead (64-bit seeds, sample ranges near 2^32, sums continued over
-two calls, constant draw words) and the event counters; SWEEP_REUSE=1 keeps one context per
+two calls, constant draw words) and the event counters; SWEEP_ROOMS=1 draws small all-diffuse
+rooms with black lights (the scenes of the two-pixels-per-lane kernel); SWEEP_REUSE=1 keeps one context per
 kernel variant for the whole sweep.
 """
 import os
@@ -78,6 +79,36 @@ def random_scene(seed):
     return Scene(width=w, height=h, ray_depth=int(rng.integers(1, 10)), n_samples=int(rng.integers(1, 4)),
                  background=f(rng.uniform(0, 1, 3) * (rng.random() < 0.5)), cam_pos=cam, cam_right=f(right), cam_up=f(up),
                  cam_forward=f(fwd), fov_x=float(np.float32(rng.uniform(0.3, 2.0))), prims=list(prims))
+
+
+def room_scene(seed):
+    """Small all-diffuse rooms whose lights are black (no COLOR, as in the reference's scene): the
+    scenes the two-pixels-per-lane scan kernel is chosen for.  1 to 16 objects, 1 to 5 lights of
+    both kinds, images up to 70 pixels wide (several 16 x 8 work units, ragged edges), up to 40
+    samples (the hand-over pool gets used)."""
+    rng = np.random.default_rng(seed + 7_000_000)
+    f = lambda a: tuple(float(np.float32(v)) for v in a)
+    room = float(rng.choice([5.0, 8.0]))
+    axes = [(0, 1, 0), (0, -1, 0), (1, 0, 0), (-1, 0, 0), (0, 0, 1), (0, 0, -1)]
+    prims = [Prim(_abi.PLANE, f(a), position=f(-np.array(a) * room), color=f(rng.uniform(0.2, 1, 3)))
+             for a in axes[:int(rng.integers(3, 7))]]
+    n_lights = int(rng.integers(1, 6))
+    n_obj = int(rng.integers(n_lights, 17 - len(prims)))
+    for k in range(n_obj):
+        kind = _abi.ELLIPSOID if rng.random() < 0.5 else _abi.BOX
+        size = f(rng.choice([0.25, 0.5, 1.0, 2.0], size=3)) if rng.random() < 0.3 else f(rng.uniform(0.1, room / 3, size=3))
+        q = rng.normal(size=4)
+        rot = (0, 0, 0, 1) if rng.random() < 0.5 else normalize_quaternion(*f(q / np.linalg.norm(q)))
+        pos = f(rng.uniform(-room * 0.8, room * 0.8, size=3))
+        if k < n_lights:
+            prims.append(Prim(kind, size, position=pos, rotation=rot, emission=f(rng.uniform(0.5, 10.0, size=3))))
+        else:
+            prims.append(Prim(kind, size, position=pos, rotation=rot, color=f(rng.uniform(0.0, 1.0, size=3))))
+    rng.shuffle(prims)
+    return Scene(width=int(rng.integers(1, 71)), height=int(rng.integers(1, 41)), ray_depth=int(rng.integers(1, 9)),
+                 n_samples=int(rng.choice([1, 2, 3, 5, 17, 40])), background=(0.0, 0.0, 0.0),
+                 cam_pos=(0.0, 0.0, room * 0.9), cam_right=(1, 0, 0), cam_up=(0, 1, 0), cam_forward=(0, 0, -1),
+                 fov_x=float(np.float32(rng.uniform(0.5, 1.8))), prims=list(prims))
 
 
 FEATURES = ("scale", "negsize", "zerosize", "zeroplane", "farpos", "quat", "negquat", "lights", "ior", "color",
@@ -198,6 +229,8 @@ def main():
     if os.environ.get("SWEEP_EXTREME"):     # "1" = every oddity, or a comma-separated list of FEATURES ("" entries allowed)
         feats = None if os.environ["SWEEP_EXTREME"] == "1" else [x for x in os.environ["SWEEP_EXTREME"].split(",") if x]
         make = lambda seed: extreme_scene(seed, feats)
+    if os.environ.get("SWEEP_ROOMS") == "1":
+        make = room_scene
     big = int(os.environ.get("SWEEP_BIG", "1"))   # image edge and sample count multiplier
     options = os.environ.get("SWEEP_OPTIONS") == "1"
     reuse = os.environ.get("SWEEP_REUSE") == "1"
