@@ -57,9 +57,20 @@ RTX_DEV void bvh_try_object(const Table &tab, int pi, V3 o, V3 d, float ray_leng
 RTX_DEV bool slab_test(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, V3 oi_lo, V3 oi_hi,
                        V3 inv, float t_limit, float &t_near)
 {
+#ifdef RTX_BVH_PACKED_SLABS
+    // the low and the high plane of an axis in one packed FMA (v_pk_fma_f32): the same IEEE operations as
+    // two scalar ones; measured no faster (10 000 objects: 163.4 ms against 162.4), so not the default
+    const F2 px = {(float)lx, (float)hx}, py = {(float)ly, (float)hy}, pz = {(float)lz, (float)hz};
+    const F2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+    const F2 ox = {-oi_lo.x, -oi_hi.x}, oy = {-oi_lo.y, -oi_hi.y}, oz = {-oi_lo.z, -oi_hi.z};
+    const F2 rx = __builtin_elementwise_fma(px, ix, ox), ry = __builtin_elementwise_fma(py, iy, oy),
+             rz = __builtin_elementwise_fma(pz, iz, oz);
+    const float x0 = rx.x, x1 = rx.y, y0 = ry.x, y1 = ry.y, z0 = rz.x, z1 = rz.y;
+#else
     float x0 = __builtin_fmaf((float)lx, inv.x, -oi_lo.x), x1 = __builtin_fmaf((float)hx, inv.x, -oi_hi.x);
     float y0 = __builtin_fmaf((float)ly, inv.y, -oi_lo.y), y1 = __builtin_fmaf((float)hy, inv.y, -oi_hi.y);
     float z0 = __builtin_fmaf((float)lz, inv.z, -oi_lo.z), z1 = __builtin_fmaf((float)hz, inv.z, -oi_hi.z);
+#endif
     float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
     t_near = tn;
