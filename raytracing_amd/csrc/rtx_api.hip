@@ -1280,7 +1280,8 @@ int rtx_last_kernel_ms(rtx_ctx *c, float *ms)
     if (!c->timed) return fail(RTX_ERR_NO_SCENE, "nothing has been rendered yet");
     // a multi-GPU context: its GPUs run side by side, the render takes as long as the slowest
     float worst = 0.0f;
-    for (rtx_ctx *w : workers_of(c)) {
+    for (size_t i = 0; i <= c->peers.size(); ++i) {
+        rtx_ctx *w = i == 0 ? c : c->peers[i - 1];
         if (!w->timed) continue;
         DeviceGuard g(w->device);
         float one = 0.0f;
