@@ -461,6 +461,9 @@ void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
     P.seed_hi = (uint32_t)(c->opts.seed >> 32);
     P.rng_const = c->opts.rng_mode == RTX_RNG_CONST ? 1u : 0u;
     P.stop_on_zero = scene_is_tame(c->scene, c->prims) ? 1u : 0u;
+    P.ellipsoids_pow2 = 1u;
+    for (const rtx_prim &p : c->prims)
+        if (p.kind == RTX_ELLIPSOID && !is_pow2_param(p)) P.ellipsoids_pow2 = 0u;
     {
         // Scenes like the reference's own (assets/scene.txt): a few diffuse objects and lights without a
         // COLOR line, i.e. black ones, at which every path that reaches them ends (see stop_on_zero).

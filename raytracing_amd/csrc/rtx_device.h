@@ -68,6 +68,7 @@ struct RenderParams {
     // the identity; and where a recording launch leaves each tile's cost (nullptr: not recorded).
     const uint32_t *tile_order;
     uint32_t *tile_cost;
+    uint32_t ellipsoids_pow2;      // 1: every ellipsoid's radii are powers of two (kGeomPow2)
     uint32_t paths_end_at_lights;  // 1: a small all-diffuse scene whose lights are black (set at upload; picks the two-pixel scan kernel)
     uint32_t pool_entries;  // megakernel: float4 entries of a wave's hand-over pool in LDS (set by the launcher)
     BvhView bvh;

@@ -57,6 +57,7 @@ RTX_DEV Table stage_table_lds(const RenderParams &P)
     t.light_bounds = P.light_bounds;
     t.n_prims = P.n_prims;
     t.n_lights = P.n_lights;
+    t.ellipsoids_pow2 = P.ellipsoids_pow2 != 0u;
     return t;
 }
 RTX_DEV Table global_table(const RenderParams &P)
@@ -68,6 +69,7 @@ RTX_DEV Table global_table(const RenderParams &P)
     t.light_bounds = P.light_bounds;
     t.n_prims = P.n_prims;
     t.n_lights = P.n_lights;
+    t.ellipsoids_pow2 = P.ellipsoids_pow2 != 0u;
     return t;
 }
 

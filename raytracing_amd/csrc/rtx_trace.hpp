@@ -42,6 +42,7 @@ struct Table {
     const int32_t *lights;
     const float4 *light_bounds;  // two per light: (bounding-sphere centre xyz, squared radius), (slack, -, -, -)
     uint32_t n_prims, n_lights;
+    bool ellipsoids_pow2;   // every ellipsoid's radii are powers of two (kGeomPow2): their normals need no division
 };
 
 struct Geom {
@@ -163,11 +164,17 @@ RTX_DEV bool figure_t(int kind, V3 param, const LocalRay &r, float &t)
     if (kind == kEllipsoidPow2) return ellipsoid_t(param, r, t, true);
     return box_t(param, r, t);
 }
-// Local (unnormalised) normal at distance t.
-RTX_DEV V3 figure_normal(int kind, V3 param, const LocalRay &r, float t)
+// Local (unnormalised) normal at distance t.  `pow2` (the same in every lane): every component of
+// an ellipsoid's param is a power of two (kGeomPow2), so the nine divisions are exact products (see
+// div_param).
+RTX_DEV V3 figure_normal(int kind, V3 param, const LocalRay &r, float t, bool pow2 = false)
 {
     if (kind == kPlane) return param;
     if (kind == kEllipsoid) {
+        if (pow2) {
+            const V3 inv = pow2_inverse(param);
+            return cmul(cmul(r.o, inv) + cmul(r.d, inv) * t, inv);
+        }
         V3 u = cdiv(r.o, param);
         V3 v = cdiv(r.d, param);
         return cdiv(u + v * t, param);
@@ -238,7 +245,7 @@ RTX_DEV Hit finish_hit(const Table &tab, int idx, V3 o, V3 d, float t, bool want
     Geom g = load_geom(tab.geom, (uint32_t)idx);
     LocalRay lr = to_local(g, o, d);
     Hit h;
-    h.n = world_normal(g, figure_normal(g.kind, g.param, lr, t), d);
+    h.n = world_normal(g, figure_normal(g.kind, g.param, lr, t, tab.ellipsoids_pow2), d);
     h.inside = want_inside ? figure_inside(g.kind, g.param, lr.o) : false;
     return h;
 }
@@ -312,11 +319,11 @@ RTX_DEV float intersection_pdf(const Geom &g, float box_area_pdf, V3 o, V3 d, fl
 // candidates, lowest index first, which keeps the order of the additions.
 // MANY_LIGHTS selects the candidate-mask form at compile time (kernels are instantiated both
 // ways and the launcher picks by light count), so few-light scenes do not carry its registers.
+// `d` = the direction normalised once (Ray::new, src/ray.rs:11-16); the caller has it already.
 template <bool STATS, bool MANY_LIGHTS>
-RTX_DEV float light_pdf(const Table &tab, V3 p, V3 dir, Counters<STATS> &cnt)
+RTX_DEV float light_pdf(const Table &tab, V3 p, V3 d, Counters<STATS> &cnt)
 {
     if (tab.n_lights == 0) return 0.0f;
-    V3 d = normalize(dir);
     float pdf = 0.0f;
     if constexpr (!MANY_LIGHTS) {
         for (uint32_t li = 0; li < tab.n_lights; ++li) {
@@ -399,12 +406,14 @@ RTX_DEV float light_pdf(const Table &tab, V3 p, V3 dir, Counters<STATS> &cnt)
     return tab.n_lights == 1 ? pdf : pdf / (float)tab.n_lights;
 }
 // src/random.rs:143-161
+// d = the sampled direction as drawn, d_unit = normalize(d): the cosine pdf takes the former
+// (src/random.rs:55-57), the light pdf builds a ray from it, which normalises it (src/random.rs:88).
 template <bool STATS, bool MANY_LIGHTS>
-RTX_DEV float mis_pdf(const Table &tab, V3 p, V3 n, V3 d, Counters<STATS> &cnt)
+RTX_DEV float mis_pdf(const Table &tab, V3 p, V3 n, V3 d, V3 d_unit, Counters<STATS> &cnt)
 {
     float a = tab.n_lights == 0 ? 1.0f : 0.5f;
     float cos_pdf = rmax(dot(n, d), 0.0f) / kPi;
-    return cos_pdf * a + light_pdf<STATS, MANY_LIGHTS>(tab, p, d, cnt) * (1.0f - a);
+    return cos_pdf * a + light_pdf<STATS, MANY_LIGHTS>(tab, p, d_unit, cnt) * (1.0f - a);
 }
 
 // ------------------------------------------------------------------ sampling
@@ -556,9 +565,11 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
         }
         if (dot(new_dir, n) < 0.0f) return true;
         cnt.template add<C_PDF_EVALS>();
-        float pdf = mis_pdf<STATS, MANY_LIGHTS>(tab, point, n, new_dir, cnt);
-        if (!finite_f(pdf) || pdf < 1e-6f) return true;
+        // Ray::new inside the light pdf and Ray::new_shifted for the next segment (src/trace.rs:43)
+        // normalise the same vector: once here
         V3 nd = normalize(new_dir);
+        float pdf = mis_pdf<STATS, MANY_LIGHTS>(tab, point, n, new_dir, nd, cnt);
+        if (!finite_f(pdf) || pdf < 1e-6f) return true;
         float cosv = dot(n, nd);
         p.T = (cmul(p.T, color_obj) * cosv) / pdf;
         p.o = point + nd * kRayEps;

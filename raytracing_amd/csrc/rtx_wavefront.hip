@@ -393,6 +393,7 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
     Table tab;
     tab.n_prims = P.n_prims;
     tab.n_lights = P.n_lights;
+    tab.ellipsoids_pow2 = P.ellipsoids_pow2 != 0u;
     tab.light_bounds = P.light_bounds;
     if constexpr (SRC == kSrcLds) {
         float4 *tbl = rtx_smem + kQueueVec + kRecVec;
