@@ -276,6 +276,46 @@ bool is_pow2_param(const rtx_prim &p)
     return true;
 }
 
+// a plane in the identity pose whose normal is +-1 along one axis and +-0 along the two others:
+// the axis' flag, or 0 (rtx_trace.hpp: plane_axis_t)
+int axis_plane_flag(const rtx_prim &p)
+{
+    if (p.kind != RTX_PLANE || !is_identity_pose(p)) return 0;
+    int axis = -1;
+    for (int k = 0; k < 3; ++k) {
+        if (p.param[k] == 0.0f) continue;
+        if (std::fabs(p.param[k]) != 1.0f || axis >= 0) return 0;
+        axis = k;
+    }
+    if (axis < 0) return 0;
+    return axis == 0 ? rtx::kGeomAxisX : (axis == 1 ? rtx::kGeomAxisY : rtx::kGeomAxisZ);
+}
+
+// a box in the identity pose with half-sizes in (0, 1e30): points sampled on its surface skip the
+// rotation (rtx_trace.hpp: light_surface_sample)
+bool is_plain_box(const rtx_prim &p)
+{
+    if (p.kind != RTX_BOX || !is_identity_pose(p)) return false;
+    for (int k = 0; k < 3; ++k)
+        if (!(p.param[k] > 0.0f && p.param[k] < 1e30f)) return false;
+    return true;
+}
+
+int scan_category_of(const rtx_prim &p)
+{
+    const bool identity = is_identity_pose(p), pow2 = is_pow2_param(p);
+    if (p.kind == RTX_PLANE) {
+        const int axis = axis_plane_flag(p);
+        if (axis == rtx::kGeomAxisX) return rtx::kCatPlaneX;
+        if (axis == rtx::kGeomAxisY) return rtx::kCatPlaneY;
+        if (axis == rtx::kGeomAxisZ) return rtx::kCatPlaneZ;
+        return identity ? rtx::kCatPlaneIdentity : rtx::kCatPlane;
+    }
+    if (p.kind == RTX_BOX) return identity ? rtx::kCatBoxIdentity : rtx::kCatBox;
+    if (identity) return pow2 ? rtx::kCatEllipsoidIdentityPow2 : rtx::kCatEllipsoidIdentity;
+    return pow2 ? rtx::kCatEllipsoidPow2 : rtx::kCatEllipsoid;
+}
+
 // Every number finite and moderate, no degenerate object: the condition under which a path
 // with zero throughput may be ended (rtx_trace.hpp: bounce).  Magnitude limits keep every
 // intermediate of the trace loop finite, so the zero cannot meet an inf or a NaN later on.
@@ -343,7 +383,7 @@ int validate_scene(const rtx_scene *s)
 // context uploads the same bytes and points its kernel parameters into its own copy.
 struct SceneBlock {
     std::vector<unsigned char> bytes;
-    size_t off_mat = 0, off_lights = 0, off_lbound = 0, off_nodes = 0, off_planes = 0;
+    size_t off_mat = 0, off_lights = 0, off_lbound = 0, off_nodes = 0, off_planes = 0, off_order = 0;
     rtx::RenderParams params{};   // everything but the device pointers
 };
 
@@ -362,7 +402,9 @@ void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
     const size_t node_bytes = align16(bvh.nodes.size() * sizeof(uint4));
     const size_t plane_bytes = align16(bvh.planes.size() * sizeof(int32_t));
 
-    const size_t total = geom_bytes + mat_bytes + light_bytes + lbound_bytes + node_bytes + plane_bytes + 16;
+    const size_t order_bytes = align16((rtx::kScanHeader + n + 2) * sizeof(int32_t));   // two entries of padding (zeros: a valid index)
+
+    const size_t total = geom_bytes + mat_bytes + light_bytes + lbound_bytes + node_bytes + plane_bytes + order_bytes + 16;
     blk.bytes.assign(total, 0);
     std::vector<unsigned char> &host = blk.bytes;
     float4 *geom = reinterpret_cast<float4 *>(host.data());
@@ -371,7 +413,8 @@ void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
     for (size_t i = 0; i < n; ++i) {
         const rtx_prim &p = c->prims[i];
         int32_t kind = (int32_t)p.kind | (is_identity_pose(p) ? (rtx::kGeomIdentity << 8) : 0) |
-                       (is_pow2_param(p) ? (rtx::kGeomPow2 << 8) : 0);
+                       (is_pow2_param(p) ? (rtx::kGeomPow2 << 8) : 0) | (axis_plane_flag(p) << 8) |
+                       (is_plain_box(p) ? (rtx::kGeomPlainBoxLight << 8) : 0);
         int32_t material = (int32_t)p.material;
         float kind_bits, mat_bits;
         std::memcpy(&kind_bits, &kind, 4);
@@ -438,6 +481,21 @@ void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
     if (!bvh.nodes.empty()) std::memcpy(host.data() + off_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(uint4));
     if (!bvh.planes.empty())
         std::memcpy(host.data() + off_planes, bvh.planes.data(), bvh.planes.size() * sizeof(int32_t));
+    // the objects by scan category (rtx_device.h: kCat*)
+    const size_t off_order = off_planes + plane_bytes;
+    {
+        int32_t *order = reinterpret_cast<int32_t *>(host.data() + off_order);
+        size_t filled = 0;
+        for (int cat = 0; cat < rtx::kScanCats; ++cat) {
+            // a BVH scene scans the objects outside the tree only (rtx_bvh_traverse.hpp: bvh_always_tested)
+            for (size_t i = 0; i < n; ++i) {
+                if (want_bvh && !std::binary_search(bvh.planes.begin(), bvh.planes.end(), (int32_t)i)) continue;
+                if (scan_category_of(c->prims[i]) == cat) order[rtx::kScanHeader + filled++] = (int32_t)i;
+            }
+            order[cat] = (int32_t)filled;
+        }
+    }
+    blk.off_order = off_order;
     blk.off_mat = geom_bytes;
     blk.off_lights = geom_bytes + mat_bytes;
     blk.off_lbound = off_lbound;
@@ -517,6 +575,7 @@ int upload_scene_block(rtx_ctx *w, const SceneBlock &blk)
     P.mat = reinterpret_cast<const float4 *>(base + blk.off_mat);
     P.lights = reinterpret_cast<const int32_t *>(base + blk.off_lights);
     P.light_bounds = reinterpret_cast<const float4 *>(base + blk.off_lbound);
+    P.scan_order = reinterpret_cast<const int32_t *>(base + blk.off_order);
     P.bvh.nodes = reinterpret_cast<const uint4 *>(base + blk.off_nodes);
     P.bvh.planes = reinterpret_cast<const int32_t *>(base + blk.off_planes);
     return RTX_OK;

@@ -43,6 +43,24 @@ RTX_DEV void bvh_try_object(const Table &tab, int pi, V3 o, V3 d, float ray_leng
     }
 }
 
+// The objects every ray is tested against (unbounded ones: planes), before the traversal.  For
+// plain rays they go category by category like the linear scan's objects (scan_by_category: in a
+// BVH scene the category list holds exactly these objects); the event-counting builds keep the
+// object-by-object loop, which counts.
+template <bool STATS>
+RTX_DEV void bvh_always_tested(const BvhView &B, const Table &tab, V3 o, V3 d, float ray_length, bool all_plain,
+                               int &best, float &best_t, Counters<STATS> &cnt)
+{
+    if constexpr (!STATS) {
+        if (all_plain && tab.order != nullptr) {
+            scan_by_category(tab, o, d, ray_length, best, best_t);
+            return;
+        }
+    }
+    for (uint32_t i = 0; i < B.n_planes; ++i)
+        bvh_try_object<STATS, true>(tab, B.planes[i], o, d, ray_length, best, best_t, cnt, all_plain);
+}
+
 // Entry distance of the ray into a node box, or "miss".  Box corners are grid coordinates
 // (16-bit integers, exact in f32); inv is the reciprocal of the ray direction in grid units,
 // oi_lo = (origin + margin) * inv and oi_hi = (origin - margin) * inv with the origin in grid
@@ -176,8 +194,7 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
     int best = -1;
     best_t = kInf;
     const bool all_plain = __ballot(!ray_is_plain(o, d)) == 0ull;
-    for (uint32_t i = 0; i < B.n_planes; ++i)
-        bvh_try_object<STATS, true>(tab, B.planes[i], o, d, ray_length, best, best_t, cnt, all_plain);
+    bvh_always_tested<STATS>(B, tab, o, d, ray_length, all_plain, best, best_t, cnt);
     if (B.n_nodes == 0) return best;
     const bool leaves_plain = all_plain && B.leaves_identity != 0u;   // wave-uniform
 

@@ -11,6 +11,7 @@
 //   lights[k]   = object index of light k (emissive ellipsoids and boxes, object order)
 //   light_bounds[2k] = bounding sphere of light k: centre xyz, squared radius inflated by 2 %
 //   light_bounds[2k+1].x = slack: the sphere counts as larger by slack * |centre - ray origin|^2
+//   scan_order[] = the objects by category (kCat*), see below
 // The scan data and the shading data are separate arrays so that the scan streams 48
 // contiguous bytes per object and never touches colours.
 #pragma once
@@ -22,7 +23,22 @@ namespace rtx {
 
 enum : int { kPlane = 0, kEllipsoid = 1, kBox = 2 };
 enum : int { kDiffuse = 0, kMetallic = 1, kDielectric = 2 };
-enum : int { kGeomIdentity = 1, kGeomPow2 = 2 };  // Geom::flags
+enum : int { kGeomIdentity = 1, kGeomPow2 = 2, kGeomAxisX = 4, kGeomAxisY = 8, kGeomAxisZ = 16, kGeomPlainBoxLight = 32 };  // Geom::flags
+constexpr int kGeomAxisMask = kGeomAxisX | kGeomAxisY | kGeomAxisZ;
+
+// The closest-hit scan visits the objects category by category, so that each category's loop holds
+// one figure's code with the pose and parameter shortcuts decided at compile time instead of a
+// dispatch per object.  scan_order[0 .. kScanCats) = end of each category in the list that
+// follows (kScanHeader entries); scan_order[kScanHeader + k] = object index, increasing within a category; two entries of
+// padding (0) at the end, which the scan's read-ahead may load.
+enum : int {
+    kCatPlaneX = 0, kCatPlaneY, kCatPlaneZ,   // kGeomAxisX / Y / Z
+    kCatPlaneIdentity, kCatPlane,
+    kCatBoxIdentity, kCatBox,
+    kCatEllipsoidIdentityPow2, kCatEllipsoidIdentity, kCatEllipsoidPow2, kCatEllipsoid,
+    kScanCats
+};
+constexpr int kScanHeader = 12;   // kScanCats rounded up to whole 16-byte words
 
 // event counters kept per lane when statistics are requested
 enum : int {
@@ -50,6 +66,7 @@ struct RenderParams {
     const float4 *mat;
     const int32_t *lights;
     const float4 *light_bounds;  // two float4 per light, see above
+    const int32_t *scan_order;   // kScanHeader + n_prims + 2 entries, 16-byte aligned, see above
     uint32_t n_prims, n_lights;
     uint32_t width, height, ray_depth;
     uint32_t sample_first, sample_count;

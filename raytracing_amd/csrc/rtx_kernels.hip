@@ -25,7 +25,7 @@ extern __shared__ float4 rtx_smem[];
 
 __host__ __device__ inline uint32_t table_lds_bytes(uint32_t n_prims, uint32_t n_lights)
 {
-    return (n_prims * 6u * (uint32_t)sizeof(float4) + n_lights * (uint32_t)sizeof(int32_t) + 15u) & ~15u;
+    return (n_prims * 6u * (uint32_t)sizeof(float4) + (n_lights + kScanHeader + n_prims + 2u) * (uint32_t)sizeof(int32_t) + 15u) & ~15u;
 }
 size_t scene_lds_bytes(uint32_t n_prims, uint32_t n_lights) { return table_lds_bytes(n_prims, n_lights); }
 // dynamic LDS every kernel of this file starts with: the object table or the traversal stacks
@@ -47,13 +47,18 @@ RTX_DEV Table stage_table_lds(const RenderParams &P)
     const uint32_t ng = 3u * P.n_prims, nm = 3u * P.n_prims;
     for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) rtx_smem[i] = P.geom[i];
     for (uint32_t i = threadIdx.x; i < nm; i += blockDim.x) rtx_smem[ng + i] = P.mat[i];
-    int32_t *sl = reinterpret_cast<int32_t *>(rtx_smem + ng + nm);
+    int32_t *so = reinterpret_cast<int32_t *>(rtx_smem + ng + nm);
+    const uint32_t no = kScanHeader + P.n_prims + 2u;
+    for (uint32_t i = threadIdx.x; i < no; i += blockDim.x) so[i] = P.scan_order[i];
+    int32_t *sl = so + no;
     for (uint32_t i = threadIdx.x; i < P.n_lights; i += blockDim.x) sl[i] = P.lights[i];
     __syncthreads();
     Table t;
     t.geom = rtx_smem;
     t.mat = rtx_smem + ng;
     t.lights = sl;
+    t.order = so;
+    t.in_lds = true;
     t.light_bounds = P.light_bounds;
     t.n_prims = P.n_prims;
     t.n_lights = P.n_lights;
@@ -66,6 +71,8 @@ RTX_DEV Table global_table(const RenderParams &P)
     t.geom = P.geom;
     t.mat = P.mat;
     t.lights = P.lights;
+    t.order = P.scan_order;
+    t.in_lds = false;
     t.light_bounds = P.light_bounds;
     t.n_prims = P.n_prims;
     t.n_lights = P.n_lights;
@@ -297,8 +304,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
                 if constexpr (RECORD) rays += 1u;
                 best = -1;
                 best_t = kInf;
-                for (uint32_t i = 0; i < P.bvh.n_planes; ++i)
-                    bvh_try_object<STATS, true>(tab, P.bvh.planes[i], p.o, p.d, ray_length, best, best_t, cnt, all_plain);
+                bvh_always_tested<STATS>(P.bvh, tab, p.o, p.d, ray_length, all_plain, best, best_t, cnt);
                 sp = 0;
                 cur = P.bvh.n_nodes ? 0 : kBvhEmpty;
                 trav = true;

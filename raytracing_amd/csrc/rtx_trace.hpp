@@ -41,6 +41,8 @@ struct Table {
     const float4 *mat;
     const int32_t *lights;
     const float4 *light_bounds;  // two per light: (bounding-sphere centre xyz, squared radius), (slack, -, -, -)
+    const int32_t *order;        // the objects by category (RenderParams::scan_order), or nullptr
+    bool in_lds;                 // geom and order are LDS copies
     uint32_t n_prims, n_lights;
     bool ellipsoids_pow2;   // every ellipsoid's radii are powers of two (kGeomPow2): their normals need no division
 };
@@ -50,7 +52,9 @@ struct Geom {
     V3 pos;
     int kind;
     int flags;   // kGeomIdentity: rotation is exactly (+0, +0, +0, 1) and the position is tame;
-                 // kGeomPow2: every component of param is a positive power of two
+                 // kGeomPow2: every component of param is a positive power of two;
+                 // kGeomAxisX/Y/Z: a plane with kGeomIdentity whose normal is +-1 along that axis, +-0 along the others;
+                 // kGeomPlainBoxLight: a box with kGeomIdentity and half-sizes in (0, 1e30)
     V3 param;
 };
 RTX_DEV Geom load_geom(const float4 *g, uint32_t i)
@@ -154,6 +158,19 @@ RTX_DEV bool box_t(V3 s, const LocalRay &r, float &t)
     if (t2 >= 0.0f) { t = t2; return true; }
     return false;
 }
+// A plane whose normal is +-e_k, for a ray that went through to_local_identity (finite components,
+// none of them -0).  The two dot products of plane_t are then s * o_k and s * d_k with s = +-1, up
+// to the sign of a zero: the other products are zeros, and a zero added to a non-zero x gives x.
+// Division rounds symmetrically in both signs, so -(s o_k) / (s d_k) has the bits of (-o_k) / d_k.
+// When o_k or d_k is zero the sign of that zero may differ from plane_t's:
+//   d_k = 0: t is an infinity or a NaN either way, and both are rejected by the range filter;
+//   o_k = 0: t is a zero of either sign, accepted either way, and t only enters comparisons and
+//   the hit point o + d * t, where d * (+-0) is a zero added to components that are not -0.
+RTX_DEV bool plane_axis_t(float o_k, float d_k, float &t)
+{
+    t = -o_k / d_k;
+    return !(t < 0.0f);
+}
 // `kind` may carry kGeomPow2 << 8 (wave-uniform callers only): an ellipsoid whose radii are
 // powers of two is one more case of the dispatch, so other objects pay nothing for it.
 constexpr int kEllipsoidPow2 = kEllipsoid | (kGeomPow2 << 8);
@@ -203,6 +220,81 @@ RTX_DEV V3 world_normal(const Geom &g, V3 n_local, V3 d_world)
     return n;
 }
 
+// One category of the scan: every lane tests the same object, `CAT` fixes the figure, whether
+// the pose is the identity (callers pass plain rays only, see ray_is_plain) and the parameter
+// shortcut.  Categories are visited out of object order, so among equal distances the lowest
+// index is kept explicitly -- what "the first object reaching the minimum keeps it" comes to.
+template <int CAT>
+RTX_DEV void scan_category(const Table &tab, uint32_t begin, uint32_t end, V3 o, V3 d, float ray_length, int &best,
+                           float &best_t)
+{
+    constexpr bool identity = CAT == kCatPlaneX || CAT == kCatPlaneY || CAT == kCatPlaneZ || CAT == kCatPlaneIdentity ||
+                              CAT == kCatBoxIdentity || CAT == kCatEllipsoidIdentityPow2 || CAT == kCatEllipsoidIdentity;
+    if (begin >= end) return;
+    // Two loads ahead of the arithmetic: while object k is tested, the data of object k + 1 and
+    // the index of object k + 2 are on their way, so the wave does not sit through an LDS round
+    // trip (two, with the indirection) per object.  The list is padded with two valid entries.
+    const int32_t *order = tab.order + kScanHeader;
+    auto index_at = [&](uint32_t k) {
+        const int i = order[k];
+        return tab.in_lds ? i : __builtin_amdgcn_readfirstlane(i);   // a global table is read with scalar loads
+    };
+    int i_next = index_at(begin);
+    int i_next2 = index_at(begin + 1u);
+    Geom g_next = load_geom(tab.geom, (uint32_t)i_next);
+    for (uint32_t k = begin; k < end; ++k) {
+        const int i = i_next;
+        const Geom g = g_next;
+        i_next = i_next2;
+        g_next = load_geom(tab.geom, (uint32_t)i_next);
+        i_next2 = index_at(k + 2u);
+        const LocalRay lr = identity ? to_local_identity(g, o, d) : to_local(g, o, d);
+        float t;
+        bool hit;
+        if constexpr (CAT == kCatPlaneX) hit = plane_axis_t(lr.o.x, lr.d.x, t);
+        else if constexpr (CAT == kCatPlaneY) hit = plane_axis_t(lr.o.y, lr.d.y, t);
+        else if constexpr (CAT == kCatPlaneZ) hit = plane_axis_t(lr.o.z, lr.d.z, t);
+        else if constexpr (CAT == kCatPlaneIdentity || CAT == kCatPlane) hit = plane_t(g.param, lr, t);
+        else if constexpr (CAT == kCatBoxIdentity || CAT == kCatBox) hit = box_t(g.param, lr, t);
+        else hit = ellipsoid_t(g.param, lr, t, CAT == kCatEllipsoidIdentityPow2 || CAT == kCatEllipsoidPow2);
+        hit = hit && (t * ray_length < kInf);
+        if (hit && (t < best_t || (t == best_t && i < best))) {
+            best_t = t;
+            best = i;
+        }
+    }
+}
+template <int CAT>
+RTX_DEV void scan_categories_from(const Table &tab, const uint32_t (&ends)[kScanHeader], uint32_t begin, V3 o, V3 d,
+                                  float ray_length, int &best, float &best_t)
+{
+    if constexpr (CAT < kScanCats) {
+        scan_category<CAT>(tab, begin, ends[CAT], o, d, ray_length, best, best_t);
+#ifdef RTX_X_REPEAT_CATS   // timing experiment: the categories of this bit mask run twice
+        if constexpr (((RTX_X_REPEAT_CATS) >> CAT) & 1) {
+            asm volatile("" : "+v"(o.x), "+v"(d.x));
+            scan_category<CAT>(tab, begin, ends[CAT], o, d, ray_length, best, best_t);
+        }
+#endif
+        scan_categories_from<CAT + 1>(tab, ends, ends[CAT], o, d, ray_length, best, best_t);
+    }
+}
+RTX_DEV void scan_by_category(const Table &tab, V3 o, V3 d, float ray_length, int &best, float &best_t)
+{
+    // the category ends in one round trip (the list is 16-byte aligned)
+    const uint4 *header = reinterpret_cast<const uint4 *>(tab.order);
+    uint32_t ends[kScanHeader];
+#pragma unroll
+    for (int q = 0; q < kScanHeader / 4; ++q) {
+        const uint4 e = header[q];
+        ends[4 * q + 0] = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x);
+        ends[4 * q + 1] = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+        ends[4 * q + 2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z);
+        ends[4 * q + 3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w);
+    }
+    scan_categories_from<0>(tab, ends, 0u, o, d, ray_length, best, best_t);
+}
+
 // Closest hit over the whole table, linear scan in object order.  The first object
 // reaching the minimum keeps it (strict <).  `i` is wave-uniform, so the table reads
 // are broadcasts (LDS) or scalar loads (global).
@@ -214,6 +306,10 @@ RTX_DEV int closest_hit_scan(const Table &tab, V3 o, V3 d, float &best_t)
     best_t = kInf;
     // wave-uniform: every active lane's ray is plain
     const bool all_plain = UNIFORM_KIND && __ballot(!ray_is_plain(o, d)) == 0ull;
+    if (UNIFORM_KIND && all_plain && tab.order != nullptr) {
+        scan_by_category(tab, o, d, ray_length, best, best_t);
+        return best;
+    }
     for (uint32_t i = 0; i < tab.n_prims; ++i) {
         Geom g = load_geom(tab.geom, i);
         LocalRay lr;
@@ -417,29 +513,43 @@ RTX_DEV float mis_pdf(const Table &tab, V3 p, V3 n, V3 d, V3 d_unit, Counters<ST
 }
 
 // ------------------------------------------------------------------ sampling
-// src/random.rs:33-53
-RTX_DEV V3 cosine_sample(V3 n, uint32_t w_theta, uint32_t w_r)
+// src/random.rs:33-53 in two steps.  The cosine-weighted direction ends with normalising
+// cross(xi, n), the light-sampled one (src/random.rs:76-80) with normalising the vector to the
+// sampled point: the caller runs that one normalisation for both kinds of lanes together.
+struct CosineDraw {
+    float x, y, z;   // the point on the unit hemisphere
+    V3 xi;           // first tangent
+};
+// returns cross(xi, n), whose normalisation is the second tangent
+RTX_DEV V3 cosine_sample_begin(V3 n, uint32_t w_theta, uint32_t w_r, CosineDraw &c)
 {
     float theta = gen_range(w_theta, 0.0f, 2.0f * kPi);
     float r = __builtin_sqrtf(gen_range(w_r, 0.0f, 1.0f));
     float st, ct;
     sincos_2pi(theta, st, ct);
-    float x = r * ct;
-    float y = r * st;
-    float z = __builtin_sqrtf(1.0f - x * x - y * y);
+    c.x = r * ct;
+    c.y = r * st;
+    c.z = __builtin_sqrtf(1.0f - c.x * c.x - c.y * c.y);
 
     float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
     float m = rmin(rmin(ax, ay), az);
     V3 xi = v3(ax > m ? 0.0f : 1.0f, ay > m ? 0.0f : 1.0f, az > m ? 0.0f : 1.0f);
-    xi = normalize(xi - n * dot(xi, n));
-    V3 yi = normalize(cross(xi, n));
-    return v3((xi.x * x + yi.x * y) + n.x * z,
-              (xi.y * x + yi.y * y) + n.y * z,
-              (xi.z * x + yi.z * y) + n.z * z);
+    c.xi = normalize(xi - n * dot(xi, n));
+    return cross(c.xi, n);
+}
+RTX_DEV V3 cosine_sample_end(const CosineDraw &c, V3 yi, V3 n)
+{
+    return v3((c.xi.x * c.x + yi.x * c.y) + n.x * c.z,
+              (c.xi.y * c.x + yi.y * c.y) + n.y * c.z,
+              (c.xi.z * c.x + yi.z * c.y) + n.z * c.z);
 }
 // src/objects/sample.rs:13-17 over :25-51 (box) and :60-64, :78-85 (ellipsoid).
 // Word 0 of the draw block: bit 30 = the face sign; words 1..3: the floats.
-RTX_DEV V3 light_surface_sample(const Geom &g, uint4 w)
+// plain_boxes (the same in every lane): each lane's light has kGeomPlainBoxLight -- a box in the
+// identity pose with moderate half-sizes.  Its surface point is finite and has no -0 component
+// (u * 2a - a and +-b with b > 0 never give one), so the identity rotation would return it bit
+// for bit (see ray_is_plain) and is skipped.
+RTX_DEV V3 light_surface_sample(const Geom &g, uint4 w, bool plain_boxes)
 {
     V3 point;
     if (g.kind == kBox) {
@@ -470,6 +580,7 @@ RTX_DEV V3 light_surface_sample(const Geom &g, uint4 w)
         float y = __builtin_sqrtf(1.0f - z * z) * sp;
         point = cmul(v3(x, y, z), g.param);
     }
+    if (plain_boxes) return point + g.pos;
     return rotate(g.rot, point) + g.pos;
 }
 
@@ -551,18 +662,24 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
         float4 m2 = tab.mat[3 * idx + 2];
         V3 color_obj = v3(m2.x, m2.y, m2.z);  // color / pi, divided at upload
         uint4 w = draw_block(P, pixel, sample, p.depth + 1);
-        V3 new_dir;
+        // v = the vector whose normalisation both kinds of sample end with (see cosine_sample_begin)
+        V3 v;
+        CosineDraw cd;
         bool pick_cosine = tab.n_lights == 0 || (w.x >> 31) == 0u;
         if (pick_cosine) {
             cnt.template add<C_COSINE>();
-            new_dir = cosine_sample(n, w.y, w.z);
+            v = cosine_sample_begin(n, w.y, w.z, cd);
         } else {
             uint32_t li = __umulhi(w.x << 2, tab.n_lights);
             Geom lg = load_geom(tab.geom, (uint32_t)tab.lights[li]);
             cnt.template add<C_LSAMPLE_ELLIPSOID>(lg.kind == kEllipsoid);
             cnt.template add<C_LSAMPLE_BOX>(lg.kind == kBox);
-            new_dir = normalize(light_surface_sample(lg, w) - point);
+            const bool plain_boxes = __ballot(!(lg.flags & kGeomPlainBoxLight)) == 0ull;
+            v = light_surface_sample(lg, w, plain_boxes) - point;
         }
+        const V3 u = normalize(v);
+        V3 new_dir = u;
+        if (pick_cosine) new_dir = cosine_sample_end(cd, u, n);
         if (dot(new_dir, n) < 0.0f) return true;
         cnt.template add<C_PDF_EVALS>();
         // Ray::new inside the light pdf and Ray::new_shifted for the next segment (src/trace.rs:43)

@@ -367,8 +367,7 @@ RTX_DEV void wf_extend_bvh(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPix
                     ray_length = len(d);
                     best = -1;
                     best_t = kInf;
-                    for (uint32_t i = 0; i < B.n_planes; ++i)
-                        bvh_try_object<STATS, true>(tab, B.planes[i], o, d, ray_length, best, best_t, cnt, all_plain);
+                    bvh_always_tested<STATS>(B, tab, o, d, ray_length, all_plain, best, best_t, cnt);
                     R = bvh_ray_setup(B, o, d);
                     sp = 0;
                     cur = B.n_nodes ? 0 : kBvhEmpty;
@@ -395,16 +394,22 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
     tab.n_lights = P.n_lights;
     tab.ellipsoids_pow2 = P.ellipsoids_pow2 != 0u;
     tab.light_bounds = P.light_bounds;
+    tab.order = P.scan_order;
+    tab.in_lds = SRC == kSrcLds;
     if constexpr (SRC == kSrcLds) {
         float4 *tbl = rtx_smem + kQueueVec + kRecVec;
         const uint32_t ng = 3u * P.n_prims, nm = 3u * P.n_prims;
         for (uint32_t i = threadIdx.x; i < ng; i += blockDim.x) tbl[i] = P.geom[i];
         for (uint32_t i = threadIdx.x; i < nm; i += blockDim.x) tbl[ng + i] = P.mat[i];
-        int32_t *sl = reinterpret_cast<int32_t *>(tbl + ng + nm);
+        int32_t *so = reinterpret_cast<int32_t *>(tbl + ng + nm);
+        const uint32_t no = kScanHeader + P.n_prims + 2u;
+        for (uint32_t i = threadIdx.x; i < no; i += blockDim.x) so[i] = P.scan_order[i];
+        int32_t *sl = so + no;
         for (uint32_t i = threadIdx.x; i < P.n_lights; i += blockDim.x) sl[i] = P.lights[i];
         tab.geom = tbl;
         tab.mat = tbl + ng;
         tab.lights = sl;
+        tab.order = so;
     } else {
         tab.geom = P.geom;
         tab.mat = P.mat;

@@ -486,6 +486,30 @@ def test_rays_with_negative_zero_or_axis_aligned_components(oracle):
     assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
 
 
+def test_axis_planes_through_the_ray_origin_or_parallel_to_the_ray(oracle):
+    """Planes whose normal is a coordinate axis take one subtraction and one division instead of
+    two dot products.  Origins exactly on such a plane (distance +-0), rays exactly parallel to it
+    (distance inf or NaN) and normals of either sign must leave the oracle's bits, for random and
+    for constant draw words (the latter put a whole pixel column on d.x = 0)."""
+    from raytracing_amd import Prim
+    cams = [(0.0, -5.0, 15.0), (5.0, 0.0, 15.0), (-5.0, 5.0, 4.0), (0.0, 0.0, -5.0), (0.0, 0.0, 15.0)]
+    for cam in cams:
+        for words in (None, (0, 0, 0, 0)):
+            sc = reference_scene(width=34, height=18, n_samples=3).replace(cam_pos=cam)
+            # a second plane through the origin with the opposite normal, and a non-unit axis plane
+            sc.prims.append(Prim(_abi.PLANE, (0.0, 0.0, -1.0), position=(0.0, 0.0, cam[2]), color=(0.5, 0.6, 0.7)))
+            sc.prims.append(Prim(_abi.PLANE, (0.0, -2.0, 0.0), position=(0.0, 4.5, 0.0), color=(0.7, 0.6, 0.5)))
+            kw = dict(seed=9)
+            if words is not None:
+                kw.update(rng_mode=_abi.RNG_CONST, const_words=words)
+            want = oracle.render(sc, order=oracle.ORDER_FORWARD, **kw)
+            for mode, accel in ((_abi.MODE_MEGAKERNEL, _abi.ACCEL_BRUTE_LDS), (_abi.MODE_MEGAKERNEL, _abi.ACCEL_BVH),
+                                (_abi.MODE_WAVEFRONT, _abi.ACCEL_BRUTE_SCALAR)):
+                with Renderer(mode=mode, accel=accel, **kw) as r:
+                    got = r.render(sc)
+                assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), (cam, words, mode, accel)
+
+
 def test_many_lights_of_both_kinds(oracle):
     """More than two lights switch the light pdf to the candidate-mask form; it must add the
     same terms in the same order (boxes and ellipsoids, rotated, overlapping, one far away)."""
