@@ -541,7 +541,7 @@ void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
     std::memcpy(P.bvh.grid_inv_step, bvh.grid_inv_step, sizeof(P.bvh.grid_inv_step));
     std::memcpy(P.bvh.grid_step, bvh.grid_step, sizeof(P.bvh.grid_step));
     P.bvh.far_slope = bvh.far_slope;
-    P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / 2);
+    P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / rtx::kBvhNodeVec);
     P.bvh.n_planes = (uint32_t)bvh.planes.size();
     P.bvh.stack_entries = (uint32_t)std::min(bvh.depth + 1, rtx::kBvhStackSize);
     {

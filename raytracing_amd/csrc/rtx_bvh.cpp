@@ -362,7 +362,7 @@ void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
         base[a] = (double)fbase;
         inv_step[a] = (double)finv;
     }
-    out.nodes.resize(order.size() * 2);
+    out.nodes.resize(order.size() * kBvhNodeVec);
     for (size_t k = 0; k < order.size(); ++k) {
         const BuildNode &nd = bld.nodes[(size_t)order[k]];
         uint32_t lo[2][3] = {{0, 0, 0}, {0, 0, 0}}, hi[2][3] = {{0, 0, 0}, {0, 0, 0}};
@@ -375,10 +375,11 @@ void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
                 hi[c][a] = grid_hi(nd.box[c].hi[a], base[a], inv_step[a]);
             }
         }
-        out.nodes[2 * k + 0] = make_uint4(lo[0][0] | lo[0][1] << 16, lo[0][2] | hi[0][0] << 16,
-                                          hi[0][1] | hi[0][2] << 16, lo[1][0] | lo[1][1] << 16);
-        out.nodes[2 * k + 1] = make_uint4(lo[1][2] | hi[1][0] << 16, hi[1][1] | hi[1][2] << 16,
-                                          (uint32_t)ref[0], (uint32_t)ref[1]);
+        auto fb = [](uint32_t q) { float f = (float)q; uint32_t b; std::memcpy(&b, &f, 4); return b; };
+        out.nodes[4 * k + 0] = make_uint4(fb(lo[0][0]), fb(hi[0][0]), fb(lo[0][1]), fb(hi[0][1]));
+        out.nodes[4 * k + 1] = make_uint4(fb(lo[0][2]), fb(hi[0][2]), (uint32_t)ref[0], (uint32_t)ref[1]);
+        out.nodes[4 * k + 2] = make_uint4(fb(lo[1][0]), fb(hi[1][0]), fb(lo[1][1]), fb(hi[1][1]));
+        out.nodes[4 * k + 3] = make_uint4(fb(lo[1][2]), fb(hi[1][2]), 0u, 0u);
     }
     out.depth = bld.depth;
 }

@@ -8,16 +8,17 @@
 // object test can report a hit (rtx_bvh.cpp: world_bounds): far from an ellipsoid that test
 // "hits" rays passing well outside it, and the scan would return those hits.
 //
-// Node layout (32 bytes, 2 x uint4; both children's boxes live in the parent so one fetch
-// decides both).  Box corners are 16-bit coordinates on a grid that spans all bounded objects:
-// world x = grid_base + q / grid_inv_step.  The traversal is bound by the number of divergent
-// memory instructions per node visit (every lane is at another node), not by arithmetic, so
-// halving the node to two 16-byte loads is worth the unpacking; the grid only has to be
-// conservative, which the builder ensures by rounding outwards with one grid unit to spare.
-//   w[0] = lo0.x | lo0.y << 16    w[1] = lo0.z | hi0.x << 16    w[2] = hi0.y | hi0.z << 16
-//   w[3] = lo1.x | lo1.y << 16    w[4] = lo1.z | hi1.x << 16    w[5] = hi1.y | hi1.z << 16
-//   w[6] = ref0   w[7] = ref1:    ref >= 0 -> inner node index; ref < 0 -> leaf holding
-//                                 object ~ref; kBvhEmpty -> no child
+// Node layout (64 bytes, 4 x 16 bytes; both children's boxes live in the parent so one visit
+// decides both).  Box corners are coordinates on a 16-bit grid that spans all bounded objects --
+// world x = grid_base + q / grid_inv_step -- stored as the f32 values of those integers: the
+// traversal is bound by its arithmetic, and unpacking 16-bit corners cost twelve conversions
+// per visit (32-byte nodes: 10 000 objects 160 ms per frame, 64-byte nodes 156 ms).  The grid
+// only has to be conservative, which the builder ensures by rounding outwards with one grid
+// unit to spare.
+//   v[0] = lo0.x, hi0.x, lo0.y, hi0.y     v[1] = lo0.z, hi0.z, ref0, ref1
+//   v[2] = lo1.x, hi1.x, lo1.y, hi1.y     v[3] = lo1.z, hi1.z, -, -
+//   ref (int bits) >= 0 -> inner node index; ref < 0 -> leaf holding object ~ref;
+//   kBvhEmpty -> no child
 // Every leaf holds exactly one object (an object test costs about five node tests, so
 // larger leaves lose).  Nodes are stored in breadth-first order, so the first K nodes are
 // the top levels.  The tree is at most kBvhMaxDepth deep: the builder switches from the
@@ -35,9 +36,10 @@ constexpr int kBvhMaxDepth = 30;
 constexpr int kBvhStackSize = 32;
 constexpr int32_t kBvhEmpty = INT32_MIN;
 constexpr int kBvhGridMax = 65535;      // largest grid coordinate
+constexpr int kBvhNodeVec = 4;          // 16-byte words per node
 
 struct BvhHost {
-    std::vector<uint4> nodes;        // 2 uint4 per node
+    std::vector<uint4> nodes;        // kBvhNodeVec per node
     float grid_base[3] = {0, 0, 0};  // world coordinate of grid coordinate 0, per axis
     float grid_inv_step[3] = {1, 1, 1};  // grid units per world unit
     float grid_step[3] = {1, 1, 1};      // world units per grid unit

@@ -61,10 +61,18 @@ RTX_DEV void bvh_always_tested(const BvhView &B, const Table &tab, V3 o, V3 d, f
         bvh_try_object<STATS, true>(tab, B.planes[i], o, d, ray_length, best, best_t, cnt, all_plain);
 }
 
+// A ray prepared for the node tests: its reciprocal direction, the negated slab offsets on the
+// node grid per axis as (low plane, high plane) pairs (see slab_test), and whether its margin is
+// so large that it takes every node.
+struct BvhRay {
+    V3 inv;
+    F2 ox, oy, oz;
+    bool far;
+};
 // Entry distance of the ray into a node box, or "miss".  Box corners are grid coordinates
-// (16-bit integers, exact in f32); inv is the reciprocal of the ray direction in grid units,
+// (integers up to 65535, exact in f32); inv is the reciprocal of the ray direction in grid units,
 // oi_lo = (origin + margin) * inv and oi_hi = (origin - margin) * inv with the origin in grid
-// units, so q * inv - oi_lo is the world-space distance at which the ray crosses the low plane
+// units (BvhRay holds them negated), so q * inv - oi_lo is the world-space distance at which the ray crosses the low plane
 // q moved outwards by the ray's margin, and likewise for the high planes (numerator and
 // denominator carry the same scale).  One fused multiply-add per plane.  Conservative: the
 // builder rounds outwards with a grid unit to spare, and the margin (closest_hit_bvh) covers
@@ -72,22 +80,20 @@ RTX_DEV void bvh_always_tested(const BvhView &B, const Table &tab, V3 o, V3 d, f
 // For a direction component of exactly 0 the products are inf - inf = NaN, which fminf / fmaxf
 // ignore: that axis then never culls (more nodes visited by such a ray, the same result); the
 // caller passes NaN offsets for an axis whose products could overflow, to the same effect.
-RTX_DEV bool slab_test(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint32_t hy, uint32_t hz, V3 oi_lo, V3 oi_hi,
-                       V3 inv, float t_limit, float &t_near)
+RTX_DEV bool slab_test(F2 px, F2 py, F2 pz, const BvhRay &R, float t_limit, float &t_near)
 {
 #ifdef RTX_BVH_PACKED_SLABS
-    // the low and the high plane of an axis in one packed FMA (v_pk_fma_f32): the same IEEE operations as
-    // two scalar ones; measured no faster (10 000 objects: 163.4 ms against 162.4), so not the default
-    const F2 px = {(float)lx, (float)hx}, py = {(float)ly, (float)hy}, pz = {(float)lz, (float)hz};
-    const F2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-    const F2 ox = {-oi_lo.x, -oi_hi.x}, oy = {-oi_lo.y, -oi_hi.y}, oz = {-oi_lo.z, -oi_hi.z};
-    const F2 rx = __builtin_elementwise_fma(px, ix, ox), ry = __builtin_elementwise_fma(py, iy, oy),
-             rz = __builtin_elementwise_fma(pz, iz, oz);
+    // the low and the high plane of an axis in one packed FMA (v_pk_fma_f32): the same IEEE operations
+    // as two scalar ones; measured no faster even with the pairs side by side in the node (10 000
+    // objects: 157.4 ms against 156.5, the wavefront variant 249 against 244), so not the default
+    const F2 ix = {R.inv.x, R.inv.x}, iy = {R.inv.y, R.inv.y}, iz = {R.inv.z, R.inv.z};
+    const F2 rx = __builtin_elementwise_fma(px, ix, R.ox), ry = __builtin_elementwise_fma(py, iy, R.oy),
+             rz = __builtin_elementwise_fma(pz, iz, R.oz);
     const float x0 = rx.x, x1 = rx.y, y0 = ry.x, y1 = ry.y, z0 = rz.x, z1 = rz.y;
 #else
-    float x0 = __builtin_fmaf((float)lx, inv.x, -oi_lo.x), x1 = __builtin_fmaf((float)hx, inv.x, -oi_hi.x);
-    float y0 = __builtin_fmaf((float)ly, inv.y, -oi_lo.y), y1 = __builtin_fmaf((float)hy, inv.y, -oi_hi.y);
-    float z0 = __builtin_fmaf((float)lz, inv.z, -oi_lo.z), z1 = __builtin_fmaf((float)hz, inv.z, -oi_hi.z);
+    float x0 = __builtin_fmaf(px.x, R.inv.x, R.ox.x), x1 = __builtin_fmaf(px.y, R.inv.x, R.ox.y);
+    float y0 = __builtin_fmaf(py.x, R.inv.y, R.oy.x), y1 = __builtin_fmaf(py.y, R.inv.y, R.oy.y);
+    float z0 = __builtin_fmaf(pz.x, R.inv.z, R.oz.x), z1 = __builtin_fmaf(pz.y, R.inv.z, R.oz.y);
 #endif
     float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), 0.0f));
     float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fmaxf(z0, z1));
@@ -97,12 +103,6 @@ RTX_DEV bool slab_test(uint32_t lx, uint32_t ly, uint32_t lz, uint32_t hx, uint3
 // a ray whose margin reaches this many grid units takes every node
 constexpr float kBvhMaxMargin = 16384.0f;
 
-// A ray prepared for the node tests: its reciprocal direction and the two slab offsets on the node
-// grid (see slab_test), and whether its margin is so large that it takes every node.
-struct BvhRay {
-    V3 inv, oi_lo, oi_hi;
-    bool far;
-};
 // The ray on the node grid, and its margin.  The node boxes bound the zone in which the
 // object tests can report a hit for origins inside the grid; the zone grows by at most
 // far_slope per world unit the origin lies outside it (rtx_bvh.cpp: world_bounds), and the
@@ -121,15 +121,18 @@ RTX_DEV BvhRay bvh_ray_setup(const BvhView &B, V3 o, V3 d)
     const float grow = B.far_slope * outside_world * 1.01f;                             // world units
     const V3 margin = v3(grow * gs.x + 4e-7f * (fabsf(og.x) + gmax), grow * gs.y + 4e-7f * (fabsf(og.y) + gmax),
                          grow * gs.z + 4e-7f * (fabsf(og.z) + gmax));                   // grid units
-    R.oi_lo = cmul(og + margin, R.inv);
-    R.oi_hi = cmul(og - margin, R.inv);
+    V3 oi_lo = cmul(og + margin, R.inv);
+    V3 oi_hi = cmul(og - margin, R.inv);
     // q * inv - oi must not overflow in either product (then it would no longer be the distance
     // to plane q): an axis on which it could -- a direction almost parallel to the planes, on a
     // grid stretched by a far-away object -- gets NaN offsets and never culls
     const float kNaN = __int_as_float(0x7fc00000);
-    if (!(fabsf(R.inv.x) * (fabsf(og.x) + margin.x + gmax) < 3e38f)) R.oi_lo.x = R.oi_hi.x = kNaN;
-    if (!(fabsf(R.inv.y) * (fabsf(og.y) + margin.y + gmax) < 3e38f)) R.oi_lo.y = R.oi_hi.y = kNaN;
-    if (!(fabsf(R.inv.z) * (fabsf(og.z) + margin.z + gmax) < 3e38f)) R.oi_lo.z = R.oi_hi.z = kNaN;
+    if (!(fabsf(R.inv.x) * (fabsf(og.x) + margin.x + gmax) < 3e38f)) oi_lo.x = oi_hi.x = kNaN;
+    if (!(fabsf(R.inv.y) * (fabsf(og.y) + margin.y + gmax) < 3e38f)) oi_lo.y = oi_hi.y = kNaN;
+    if (!(fabsf(R.inv.z) * (fabsf(og.z) + margin.z + gmax) < 3e38f)) oi_lo.z = oi_hi.z = kNaN;
+    R.ox = F2{-oi_lo.x, -oi_hi.x};
+    R.oy = F2{-oi_lo.y, -oi_hi.y};
+    R.oz = F2{-oi_lo.z, -oi_hi.z};
     // written so that a NaN counts as far
     R.far = !(fmaxf(fmaxf(margin.x, margin.y), margin.z) < kBvhMaxMargin);
     return R;
@@ -143,14 +146,12 @@ template <bool STATS, int BLOCK>
 RTX_DEV void bvh_node_step(const BvhView &B, const BvhRay &R, float best_t, int32_t &cur, int &sp, int32_t *stack,
                            Counters<STATS> &cnt)
 {
-    const uint4 *nd = B.nodes + 2 * (size_t)cur;
-    const uint4 a = nd[0], b = nd[1];
-    const int32_t r0 = (int32_t)b.z, r1 = (int32_t)b.w;
     float d0 = 0.0f, d1 = 0.0f;
-    bool h0 = slab_test(a.x & 0xffffu, a.x >> 16, a.y & 0xffffu, a.y >> 16, a.z & 0xffffu, a.z >> 16, R.oi_lo,
-                        R.oi_hi, R.inv, best_t, d0);
-    bool h1 = slab_test(a.w & 0xffffu, a.w >> 16, b.x & 0xffffu, b.x >> 16, b.y & 0xffffu, b.y >> 16, R.oi_lo,
-                        R.oi_hi, R.inv, best_t, d1);
+    const float4 *nd = reinterpret_cast<const float4 *>(B.nodes) + kBvhNodeVec * (size_t)cur;
+    const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
+    const int32_t r0 = __float_as_int(b.z), r1 = __float_as_int(b.w);
+    bool h0 = slab_test(F2{a.x, a.y}, F2{a.z, a.w}, F2{b.x, b.y}, R, best_t, d0);
+    bool h1 = slab_test(F2{c.x, c.y}, F2{c.z, c.w}, F2{e.x, e.y}, R, best_t, d1);
     h0 = (h0 || R.far) && r0 != kBvhEmpty;
     h1 = (h1 || R.far) && r1 != kBvhEmpty;
     if constexpr (STATS) cnt.v[C_NODE_TESTS] += 2;

@@ -49,7 +49,7 @@ enum : int {
 };
 
 struct BvhView {
-    const uint4 *nodes;    // 2 uint4 per node, see rtx_bvh.h
+    const uint4 *nodes;    // kBvhNodeVec 16-byte words per node, see rtx_bvh.h
     float grid_base[3];    // node boxes are in grid coordinates: q = (x - grid_base) * grid_inv_step
     float grid_inv_step[3];
     float grid_step[3];    // world units per grid unit

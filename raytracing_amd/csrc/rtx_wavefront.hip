@@ -257,7 +257,8 @@ RTX_DEV void wf_extend_bvh(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPix
     float best_t = kInf, ray_length = 0.0f;
     V3 o = v3(0.0f, 0.0f, 0.0f), d = o;
     BvhRay R;
-    R.inv = R.oi_lo = R.oi_hi = o;
+    R.inv = o;
+    R.ox = R.oy = R.oz = F2{0.0f, 0.0f};
     R.far = false;
     bool plain = true;
     bool exhausted = false;       // wave-uniform: the queue has been handed out completely
