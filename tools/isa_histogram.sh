@@ -1,10 +1,10 @@
 #!/bin/bash
 # Static instruction histogram of one kernel of rtx_kernels.hip (default: the megakernel of the
-# reference scene, k_megakernel<kSrcLds, no stats, few lights, no recording>), from the compiler's
+# reference scene, k_megakernel_scan2<kSrcLds, no stats, few lights, no recording>), from the compiler's
 # own assembly: which opcodes the VALU instructions of the kernel are made of.
 #   tools/isa_histogram.sh [mangled kernel name] > profiles/<round>/isa_histogram_<kernel>.txt
 set -e
-K=${1:-_ZN3rtx12k_megakernelILi0ELb0ELb0ELb0EEEvNS_12RenderParamsE}
+K=${1:-_ZN3rtx18k_megakernel_scan2ILi0ELb0ELb0ELb0EEEvNS_12RenderParamsE}
 cd "$(dirname "$0")/../raytracing_amd/csrc"
 S=$(mktemp /tmp/rtxXXXX.s)
 /opt/rocm/bin/hipcc -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -x hip -S --cuda-device-only -o $S rtx_kernels.hip 2>/dev/null

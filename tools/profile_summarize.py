@@ -18,7 +18,8 @@ key = "wavefront" if mode == "wavefront" else "megakernel"
 out = {}
 kernels = []
 for d in "abcd":
-    for f in glob.glob(f"{src}/{d}/*/*_counter_collection.csv"):
+    # a pass directory can hold files of earlier runs (gpurun merges into the local copy): the newest counts
+    for f in sorted(glob.glob(f"{src}/{d}/*/*_counter_collection.csv"), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             if key in r["Kernel_Name"]:
                 out[r["Counter_Name"]] = out.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
@@ -30,7 +31,7 @@ if "SQ_THREAD_CYCLES_VALU" in out:
 if "FETCH_SIZE" in out and "WRITE_SIZE" in out:
     out["hbm_bytes_per_launch"] = (2 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024
 json.dump(out, open(f"{dst}/{workload}_{mode}_pmc.json", "w"), indent=1, sort_keys=True)
-for f in glob.glob(f"{src}/trace/*/*_kernel_stats.csv"):
+for f in sorted(glob.glob(f"{src}/trace/*/*_kernel_stats.csv"), key=os.path.getmtime)[-1:]:
     shutil.copy(f, f"{dst}/{workload}_{mode}_kernel_stats.csv")
 for line in open(f"{src}/trace.log"):
     if line.startswith("{"):
