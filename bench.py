@@ -43,6 +43,9 @@ def build_workload(name, spp_override=None, size_override=None):
         sc, desc = dielectric_scene(1920, 1080, 256, 16), "dielectric/metallic scene (33 objects), 1920x1080, 256 spp, depth 16"
     elif name == "c1":
         sc, desc = reference_scene(512, 512, 10, 6), "reference scene at its native 512x512, 10 spp, depth 6"
+    elif name[0] == "s" and name[1:].isdigit():
+        # tuning aid, not a configuration of the baseline: C3's generator at another object count
+        sc, desc = synthetic_scene(int(name[1:]), 12345, 1920, 1080, 64, 6), f"synthetic {name[1:]} objects, 1920x1080, 64 spp, depth 6"
     else:
         raise SystemExit(f"unknown workload {name}")
     if size_override:

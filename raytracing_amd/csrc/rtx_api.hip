@@ -544,6 +544,10 @@ void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
     P.bvh.n_nodes = (uint32_t)(bvh.nodes.size() / rtx::kBvhNodeVec);
     P.bvh.n_planes = (uint32_t)bvh.planes.size();
     P.bvh.stack_entries = (uint32_t)std::min(bvh.depth + 1, rtx::kBvhStackSize);
+    // Measured on scenes of 33 to 40 000 objects: small trees run faster when the object tests wait for
+    // twice as many lanes as still descend, trees of a few hundred objects and more when they do not wait
+    // (60 objects: 90.3 against 92.1 ms; 200: 101.1 / 100.4; 10 000: 156.8 / 151.6; 40 000: 152.4 / 144.1)
+    P.bvh.leaf_cost = P.bvh.n_nodes >= 128u ? 1u : 2u;
     {
         // objects outside the always-tested list are the leaves
         std::vector<char> listed(n, 0);

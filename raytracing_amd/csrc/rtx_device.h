@@ -58,6 +58,7 @@ struct BvhView {
     uint32_t n_nodes, n_planes;
     uint32_t stack_entries;   // postponed nodes a traversal can hold: the tree's depth + 1
     uint32_t leaves_identity;   // 1: every object in a leaf has the identity pose (kGeomIdentity)
+    uint32_t leaf_cost;         // megakernel: lanes at a leaf wait until they outnumber the descending ones this many times
 };
 
 // kernel parameters: passed by value, so every field sits in scalar registers

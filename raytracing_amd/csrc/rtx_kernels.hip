@@ -110,7 +110,8 @@ RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, flo
 }
 
 // BVH scenes: the wave leaves its traversal loop when fewer than NUM / DEN of its active lanes are
-// still traversing; an object test is worth LEAF_COST node steps; node steps come in batches.
+// still traversing; an object test is worth LEAF_COST node steps (default: BvhView::leaf_cost,
+// chosen by the size of the tree); node steps come in batches.
 #ifndef RTX_MK_TRAV_NUM
 #define RTX_MK_TRAV_NUM 1u
 #endif
@@ -118,10 +119,10 @@ RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, flo
 #define RTX_MK_TRAV_DEN 4u
 #endif
 #ifndef RTX_MK_LEAF_COST
-#define RTX_MK_LEAF_COST 2u
+#define RTX_MK_LEAF_COST P.bvh.leaf_cost
 #endif
 #ifndef RTX_MK_NODE_BATCH
-#define RTX_MK_NODE_BATCH 4
+#define RTX_MK_NODE_BATCH 2
 #endif
 // The diffuse scatter of a hit is postponed until NUM / 64 of the wave's active lanes wait for one
 // (0: the scatter is one call for all materials, as soon as the hit is known), separately for the
