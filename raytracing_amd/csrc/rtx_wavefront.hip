@@ -219,13 +219,13 @@ RTX_DEV void wf_shade(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPixels> 
 #define RTX_WF_COST_NODE 1u      // a batch of node steps
 #endif
 #ifndef RTX_WF_COST_LEAF
-#define RTX_WF_COST_LEAF 3u      // one object test
+#define RTX_WF_COST_LEAF 2u      // one object test
 #endif
 #ifndef RTX_WF_COST_SERVE
-#define RTX_WF_COST_SERVE 6u     // write back finished rays, fetch new ones, test the plane list
+#define RTX_WF_COST_SERVE 8u     // write back finished rays, fetch new ones, test the plane list
 #endif
 #ifndef RTX_WF_NODE_BATCH
-#define RTX_WF_NODE_BATCH 2
+#define RTX_WF_NODE_BATCH 3
 #endif
 // The extend stage (src/trace.rs:12-23) for scenes with a BVH.  A traversal visits anything from
 // a handful to several hundred nodes, so dealing the active queue out in fixed portions leaves
