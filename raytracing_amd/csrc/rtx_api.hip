@@ -277,8 +277,8 @@ bool is_pow2_param(const rtx_prim &p)
 }
 
 // a plane in the identity pose whose normal is +-1 along one axis and +-0 along the two others:
-// the axis' flag, or 0 (rtx_trace.hpp: plane_axis_t)
-int axis_plane_flag(const rtx_prim &p)
+// 1 + that axis, or 0 (rtx_trace.hpp: plane_axis_t)
+int axis_plane(const rtx_prim &p)
 {
     if (p.kind != RTX_PLANE || !is_identity_pose(p)) return 0;
     int axis = -1;
@@ -287,8 +287,7 @@ int axis_plane_flag(const rtx_prim &p)
         if (std::fabs(p.param[k]) != 1.0f || axis >= 0) return 0;
         axis = k;
     }
-    if (axis < 0) return 0;
-    return axis == 0 ? rtx::kGeomAxisX : (axis == 1 ? rtx::kGeomAxisY : rtx::kGeomAxisZ);
+    return axis + 1;
 }
 
 // a box in the identity pose with half-sizes in (0, 1e30): points sampled on its surface skip the
@@ -305,10 +304,8 @@ int scan_category_of(const rtx_prim &p)
 {
     const bool identity = is_identity_pose(p), pow2 = is_pow2_param(p);
     if (p.kind == RTX_PLANE) {
-        const int axis = axis_plane_flag(p);
-        if (axis == rtx::kGeomAxisX) return rtx::kCatPlaneX;
-        if (axis == rtx::kGeomAxisY) return rtx::kCatPlaneY;
-        if (axis == rtx::kGeomAxisZ) return rtx::kCatPlaneZ;
+        const int axis = axis_plane(p);
+        if (axis != 0) return rtx::kCatPlaneX + (axis - 1);
         return identity ? rtx::kCatPlaneIdentity : rtx::kCatPlane;
     }
     if (p.kind == RTX_BOX) return identity ? rtx::kCatBoxIdentity : rtx::kCatBox;
@@ -413,7 +410,7 @@ void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
     for (size_t i = 0; i < n; ++i) {
         const rtx_prim &p = c->prims[i];
         int32_t kind = (int32_t)p.kind | (is_identity_pose(p) ? (rtx::kGeomIdentity << 8) : 0) |
-                       (is_pow2_param(p) ? (rtx::kGeomPow2 << 8) : 0) | (axis_plane_flag(p) << 8) |
+                       (is_pow2_param(p) ? (rtx::kGeomPow2 << 8) : 0) |
                        (is_plain_box(p) ? (rtx::kGeomPlainBoxLight << 8) : 0);
         int32_t material = (int32_t)p.material;
         float kind_bits, mat_bits;

@@ -23,8 +23,7 @@ namespace rtx {
 
 enum : int { kPlane = 0, kEllipsoid = 1, kBox = 2 };
 enum : int { kDiffuse = 0, kMetallic = 1, kDielectric = 2 };
-enum : int { kGeomIdentity = 1, kGeomPow2 = 2, kGeomAxisX = 4, kGeomAxisY = 8, kGeomAxisZ = 16, kGeomPlainBoxLight = 32 };  // Geom::flags
-constexpr int kGeomAxisMask = kGeomAxisX | kGeomAxisY | kGeomAxisZ;
+enum : int { kGeomIdentity = 1, kGeomPow2 = 2, kGeomPlainBoxLight = 4 };  // Geom::flags
 
 // The closest-hit scan visits the objects category by category, so that each category's loop holds
 // one figure's code with the pose and parameter shortcuts decided at compile time instead of a
@@ -32,7 +31,7 @@ constexpr int kGeomAxisMask = kGeomAxisX | kGeomAxisY | kGeomAxisZ;
 // follows (kScanHeader entries); scan_order[kScanHeader + k] = object index, increasing within a category; two entries of
 // padding (0) at the end, which the scan's read-ahead may load.
 enum : int {
-    kCatPlaneX = 0, kCatPlaneY, kCatPlaneZ,   // kGeomAxisX / Y / Z
+    kCatPlaneX = 0, kCatPlaneY, kCatPlaneZ,   // identity pose, normal +-1 along that axis and +-0 along the others
     kCatPlaneIdentity, kCatPlane,
     kCatBoxIdentity, kCatBox,
     kCatEllipsoidIdentityPow2, kCatEllipsoidIdentity, kCatEllipsoidPow2, kCatEllipsoid,

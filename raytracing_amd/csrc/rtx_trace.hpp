@@ -53,7 +53,6 @@ struct Geom {
     int kind;
     int flags;   // kGeomIdentity: rotation is exactly (+0, +0, +0, 1) and the position is tame;
                  // kGeomPow2: every component of param is a positive power of two;
-                 // kGeomAxisX/Y/Z: a plane with kGeomIdentity whose normal is +-1 along that axis, +-0 along the others;
                  // kGeomPlainBoxLight: a box with kGeomIdentity and half-sizes in (0, 1e30)
     V3 param;
 };
