@@ -147,7 +147,9 @@ RTX_DEV void bvh_node_step(const BvhView &B, const BvhRay &R, float best_t, int3
                            Counters<STATS> &cnt)
 {
     float d0 = 0.0f, d1 = 0.0f;
-    const float4 *nd = reinterpret_cast<const float4 *>(B.nodes) + kBvhNodeVec * (size_t)cur;
+    // a 32-bit byte offset from the (wave-uniform) base: the loads take it as is, no 64-bit address arithmetic
+    const float4 *nd = reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(B.nodes) +
+                                                        (uint32_t)cur * (uint32_t)(kBvhNodeVec * sizeof(uint4)));
     const float4 a = nd[0], b = nd[1], c = nd[2], e = nd[3];
     const int32_t r0 = __float_as_int(b.z), r1 = __float_as_int(b.w);
     bool h0 = slab_test(F2{a.x, a.y}, F2{a.z, a.w}, F2{b.x, b.y}, R, best_t, d0);
