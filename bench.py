@@ -234,6 +234,12 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="N = 1: only the headline workload, not the other configurations")
     args = ap.parse_args()
 
+    # Rank 0 prints ONE line on stdout.  Libraries write there too (RCCL prints a version banner
+    # when the process group comes up), so everything but the result line goes to stderr.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from raytracing_amd.flops import PEAK_FP32_VECTOR_TFLOPS
@@ -304,7 +310,8 @@ def main():
             cb = cpu_baseline(scene)
             out["cpu_baseline"] = cb
             out["speedup_vs_cpu_1thread"] = value / cb["value"]
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 
