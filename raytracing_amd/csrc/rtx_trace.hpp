@@ -657,10 +657,14 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
     V3 point = p.o + p.d * t;
     V3 n = h.n;
 
+    // Lanes of a wave may hold different materials, and what the three branches have in common is
+    // written once for all of them: the draw block of this surface interaction (the diffuse sample
+    // and the dielectric's coin take it from the same counter; a metallic surface draws nothing, a
+    // dielectric one that cannot refract ignores it) and the normalisation of the new direction.
+    uint4 w = make_uint4(0u, 0u, 0u, 0u);
+    if (material != kMetallic) w = draw_block(P, pixel, sample, p.depth + 1);
+    V3 dir;   // the new direction as the material gives it, before Ray::new_shifted normalises it
     if (material == kDiffuse) {
-        float4 m2 = tab.mat[3 * idx + 2];
-        V3 color_obj = v3(m2.x, m2.y, m2.z);  // color / pi, divided at upload
-        uint4 w = draw_block(P, pixel, sample, p.depth + 1);
         // v = the vector whose normalisation both kinds of sample end with (see cosine_sample_begin)
         V3 v;
         CosineDraw cd;
@@ -677,25 +681,13 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
             v = light_surface_sample(lg, w, plain_boxes) - point;
         }
         const V3 u = normalize(v);
-        V3 new_dir = u;
-        if (pick_cosine) new_dir = cosine_sample_end(cd, u, n);
-        if (dot(new_dir, n) < 0.0f) return true;
+        dir = u;
+        if (pick_cosine) dir = cosine_sample_end(cd, u, n);
+        if (dot(dir, n) < 0.0f) return true;
         cnt.template add<C_PDF_EVALS>();
-        // Ray::new inside the light pdf and Ray::new_shifted for the next segment (src/trace.rs:43)
-        // normalise the same vector: once here
-        V3 nd = normalize(new_dir);
-        float pdf = mis_pdf<STATS, MANY_LIGHTS>(tab, point, n, new_dir, nd, cnt);
-        if (!finite_f(pdf) || pdf < 1e-6f) return true;
-        float cosv = dot(n, nd);
-        p.T = (cmul(p.T, color_obj) * cosv) / pdf;
-        p.o = point + nd * kRayEps;
-        p.d = nd;
-        cnt.template add<C_DIFFUSE>();
     } else if (material == kMetallic) {
-        V3 nd = normalize(reflect_dir(p.d, n));
+        dir = reflect_dir(p.d, n);
         p.T = cmul(p.T, color);
-        p.o = point + nd * kRayEps;
-        p.d = nd;
         cnt.template add<C_METALLIC>();
     } else {
         float ior = m1.w;
@@ -704,22 +696,25 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
         V3 fdir;
         bool can_refract = refract_dir(p.d, n, eta, fdir);
         float coeff = schlick(eta, -dot(p.d, n));
-        bool take_refracted = false;
-        if (can_refract) {
-            uint4 w = draw_block(P, pixel, sample, p.depth + 1);
-            take_refracted = u24(w.y) < 1.0f - coeff;
-        }
-        V3 nd;
-        if (take_refracted) {
-            if (!h.inside) p.T = cmul(p.T, color);
-            nd = normalize(fdir);
-        } else {
-            nd = normalize(rdir);
-        }
-        p.o = point + nd * kRayEps;
-        p.d = nd;
+        const bool take_refracted = can_refract && u24(w.y) < 1.0f - coeff;
+        if (take_refracted && !h.inside) p.T = cmul(p.T, color);
+        dir = take_refracted ? fdir : rdir;
         cnt.template add<C_DIELECTRIC>();
     }
+    // Ray::new inside the light pdf (diffuse) and Ray::new_shifted for the next segment
+    // (src/trace.rs:43, 125, 141) normalise the same vector: once here
+    const V3 nd = normalize(dir);
+    if (material == kDiffuse) {
+        float4 m2 = tab.mat[3 * idx + 2];
+        V3 color_obj = v3(m2.x, m2.y, m2.z);  // color / pi, divided at upload
+        float pdf = mis_pdf<STATS, MANY_LIGHTS>(tab, point, n, dir, nd, cnt);
+        if (!finite_f(pdf) || pdf < 1e-6f) return true;
+        float cosv = dot(n, nd);
+        p.T = (cmul(p.T, color_obj) * cosv) / pdf;
+        cnt.template add<C_DIFFUSE>();
+    }
+    p.o = point + nd * kRayEps;
+    p.d = nd;
     // A throughput of exactly zero -- the path bounced off a black object, like the light of
     // the reference's scene, which has no COLOR -- stays zero, and every later term of the
     // radiance is T * (finite emission or background) = +-0, which changes nothing when added.
