@@ -35,7 +35,10 @@ RTX_DEV void bvh_try_object(const Table &tab, int pi, V3 o, V3 d, float ray_leng
         else lr = to_local(g, o, d);
     }
     float t;
-    bool hit = figure_t(kind, g.param, lr, t);
+    bool hit;
+    // a leaf never holds a plane (unbounded objects are on the always-tested list)
+    if constexpr (UNIFORM) hit = figure_t(kind, g.param, lr, t);
+    else hit = ellipsoid_or_box_t(kind, g.param, lr, t);
     hit = hit && (t * ray_length < kInf);
     if (hit && (best < 0 || t < best_t || (t == best_t && pi < best))) {
         best_t = t;

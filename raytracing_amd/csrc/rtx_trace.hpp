@@ -157,6 +157,40 @@ RTX_DEV bool box_t(V3 s, const LocalRay &r, float &t)
     if (t2 >= 0.0f) { t = t2; return true; }
     return false;
 }
+// ellipsoid_t or box_t for lanes that hold different kinds of object (BVH leaves, the lights of a
+// many-lights scene: never planes).  Both tests begin with six quotients -- o / r and d / r for the
+// ellipsoid, (+-s - o) / d for the box -- and a division is a dozen instructions whatever its
+// operands, so every lane picks its own operands and the six divisions run once for both kinds
+// instead of once per kind.  Each lane evaluates exactly the expressions of its kind's test.
+RTX_DEV bool ellipsoid_or_box_t(int kind, V3 s, const LocalRay &r, float &t)
+{
+    const bool box = kind == kBox;
+    float x1, x2, y1, y2, z1, z2;
+    div2(box ? s.x - r.o.x : r.o.x, box ? r.d.x : s.x, box ? -s.x - r.o.x : r.d.x, box ? r.d.x : s.x, x1, x2);
+    div2(box ? s.y - r.o.y : r.o.y, box ? r.d.y : s.y, box ? -s.y - r.o.y : r.d.y, box ? r.d.y : s.y, y1, y2);
+    div2(box ? s.z - r.o.z : r.o.z, box ? r.d.z : s.z, box ? -s.z - r.o.z : r.d.z, box ? r.d.z : s.z, z1, z2);
+    if (box) {
+        float t1 = rmax(rmax(rmin(x1, x2), rmin(y1, y2)), rmin(z1, z2));
+        float t2 = rmin(rmin(rmax(x1, x2), rmax(y1, y2)), rmax(z1, z2));
+        if (t1 > t2) return false;
+        if (t1 >= 0.0f) { t = t1; return true; }
+        if (t2 >= 0.0f) { t = t2; return true; }
+        return false;
+    }
+    const V3 u = v3(x1, y1, z1), v = v3(x2, y2, z2);
+    float a = len2(v);
+    float b = dot(u, v);
+    float c = len2(u) - 1.0f;
+    float det = b * b - a * c;
+    if (det < 0.0f) return false;
+    float sq = __builtin_sqrtf(det);
+    float r1, r2;
+    div2(-b + sq, a, -b - sq, a, r1, r2);
+    float lo = rmin(r1, r2), hi = rmax(r1, r2);
+    if (lo > 0.0f) { t = lo; return true; }
+    if (hi > 0.0f) { t = hi; return true; }
+    return false;
+}
 // A plane whose normal is +-e_k, for a ray that went through to_local_identity (finite components,
 // none of them -0).  The two dot products of plane_t are then s * o_k and s * d_k with s = +-1, up
 // to the sign of a zero: the other products are zeros, and a zero added to a non-zero x gives x.
@@ -362,7 +396,11 @@ RTX_DEV bool light_intersect_cos(const Geom &g, V3 o, V3 d, float &t, float &cos
         pow2 = (flags & kGeomPow2) != 0;
     }
     LocalRay lr = ident ? to_local_identity(g, o, d) : to_local(g, o, d);
-    if (!figure_t(g.kind | (pow2 ? kGeomPow2 << 8 : 0), g.param, lr, t)) return false;
+    if constexpr (UNIFORM) {
+        if (!figure_t(g.kind | (pow2 ? kGeomPow2 << 8 : 0), g.param, lr, t)) return false;
+    } else {
+        if (!ellipsoid_or_box_t(g.kind, g.param, lr, t)) return false;   // lights are never planes
+    }
     if (ident && __builtin_amdgcn_readfirstlane(g.kind) == kBox) {
         // Axis-aligned box: the local normal is v * e_k (k = first axis of largest |.|, the
         // other two components are +0).  The identity rotation returns it unchanged, and
