@@ -369,7 +369,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
                     cnt.template add<C_HIT_BOX>(kind == kBox);
                 }
                 if constexpr (kDiffuseNum == 0u) {
-                    done = scatter<STATS, MANY_LIGHTS>(P, tab, p, idx, t, pixel, s, cnt);
+                    done = scatter<STATS, MANY_LIGHTS, SRC == kSrcBvh>(P, tab, p, idx, t, pixel, s, cnt);
                 } else {
                     // emission, depth cut and the cheap materials at once; the diffuse scatter --
                     // direction sampling and the light pdf, most of a surface interaction's cost --
@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
                             hit_idx = idx;
                             hit_t = t;
                         } else {
-                            done = bounce<STATS, MANY_LIGHTS>(P, tab, p, idx, t, material, pixel, s, cnt);
+                            done = bounce<STATS, MANY_LIGHTS, SRC == kSrcBvh>(P, tab, p, idx, t, material, pixel, s, cnt);
                         }
                     }
                 }
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
             if (n_wait != 0u && n_wait * 64u >= n_act * kDiffuseNum) {
                 if (wait_diffuse) {
                     wait_diffuse = false;
-                    if (bounce<STATS, MANY_LIGHTS>(P, tab, p, hit_idx, hit_t, kDiffuse, pixel, s, cnt)) finish_sample();
+                    if (bounce<STATS, MANY_LIGHTS, SRC == kSrcBvh>(P, tab, p, hit_idx, hit_t, kDiffuse, pixel, s, cnt)) finish_sample();
                 }
             }
         }

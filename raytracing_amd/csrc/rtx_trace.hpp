@@ -245,6 +245,42 @@ RTX_DEV bool figure_inside(int kind, V3 param, V3 o)
     V3 q = cdiv(o, param);
     return rmax(rmax(fabsf(q.x), fabsf(q.y)), fabsf(q.z)) < 1.0f;
 }
+// figure_normal and figure_inside for lanes that hold different kinds of object.  An ellipsoid's
+// normal is ((o / r) + (d / r) t) / r and a box's (o + d t) / s; "inside" looks at o / r or o / s.
+// The last division of the normal and the division of the origin are the same instructions for
+// both kinds, so they are written once with per-lane operands; every lane evaluates exactly the
+// expressions of its own kind.  `pow2` (the same in every lane): every ellipsoid of the scene has
+// power-of-two radii, so their normals are exact products (see div_param) and only boxes divide.
+RTX_DEV V3 figure_normal_inside(int kind, V3 param, const LocalRay &r, float t, bool want_inside, bool &inside,
+                                bool pow2 = false)
+{
+    inside = false;
+    if (kind == kPlane) {
+        if (want_inside) inside = dot(param, r.o) < 0.0f;
+        return param;
+    }
+    const bool ell = kind == kEllipsoid;
+    if (pow2 && ell) {
+        if (want_inside) inside = len2(cdiv(r.o, param)) < 1.0f;
+        const V3 inv = pow2_inverse(param);
+        return cmul(cmul(r.o, inv) + cmul(r.d, inv) * t, inv);
+    }
+    V3 u = v3(0.0f, 0.0f, 0.0f), x = r.o + r.d * t;
+    if (ell || want_inside) u = cdiv(r.o, param);
+    if (ell) x = u + cdiv(r.d, param) * t;
+    V3 n = cdiv(x, param);
+    if (want_inside) inside = ell ? len2(u) < 1.0f : rmax(rmax(fabsf(u.x), fabsf(u.y)), fabsf(u.z)) < 1.0f;
+    if (!ell) {
+        // keep the first component of largest magnitude, zero the other two
+        float ax = fabsf(n.x), ay = fabsf(n.y), az = fabsf(n.z);
+        int im = 0;
+        float vm = ax;
+        if (ay > vm) { vm = ay; im = 1; }
+        if (az > vm) { vm = az; im = 2; }
+        n = v3(im == 0 ? n.x : 0.0f, im == 1 ? n.y : 0.0f, im == 2 ? n.z : 0.0f);
+    }
+    return n;
+}
 // src/objects/geometry.rs:30-33
 RTX_DEV V3 world_normal(const Geom &g, V3 n_local, V3 d_world)
 {
@@ -369,13 +405,20 @@ struct Hit {
     bool inside;
 };
 // Normal and inside flag of object `idx` for the ray that hit it at distance t.
+// MIXED: the lanes of the calling kernel usually hold objects of different kinds (BVH scenes), which
+// is what figure_normal_inside is for; kernels of small scenes keep the plain dispatch.
+template <bool MIXED = false>
 RTX_DEV Hit finish_hit(const Table &tab, int idx, V3 o, V3 d, float t, bool want_inside)
 {
     Geom g = load_geom(tab.geom, (uint32_t)idx);
     LocalRay lr = to_local(g, o, d);
     Hit h;
-    h.n = world_normal(g, figure_normal(g.kind, g.param, lr, t, tab.ellipsoids_pow2), d);
-    h.inside = want_inside ? figure_inside(g.kind, g.param, lr.o) : false;
+    if constexpr (MIXED) {
+        h.n = world_normal(g, figure_normal_inside(g.kind, g.param, lr, t, want_inside, h.inside, tab.ellipsoids_pow2), d);
+    } else {
+        h.n = world_normal(g, figure_normal(g.kind, g.param, lr, t, tab.ellipsoids_pow2), d);
+        h.inside = want_inside ? figure_inside(g.kind, g.param, lr.o) : false;
+    }
     return h;
 }
 
@@ -418,7 +461,14 @@ RTX_DEV bool light_intersect_cos(const Geom &g, V3 o, V3 d, float &t, float &cos
             return true;
         }
     }
-    V3 n = normalize(rotate(g.rot, figure_normal(g.kind, g.param, lr, t)));
+    V3 nl;
+    if constexpr (UNIFORM) {
+        nl = figure_normal(g.kind, g.param, lr, t);
+    } else {
+        bool unused;
+        nl = figure_normal_inside(g.kind, g.param, lr, t, false, unused);
+    }
+    V3 n = normalize(rotate(g.rot, nl));
     cosv = fabsf(dot(n, d));
     return true;
 }
@@ -684,14 +734,14 @@ RTX_DEV bool surface_emission(const RenderParams &P, const Table &tab, Path &p, 
 // ray: picks the next ray and updates the throughput.  Returns true when the path ends
 // here (a rejected diffuse sample).  `material` is the object's material; kernels that
 // run one material per launch pass it as a constant.
-template <bool STATS, bool MANY_LIGHTS>
+template <bool STATS, bool MANY_LIGHTS, bool MIXED = false>
 RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, float t, int material,
                     uint32_t pixel, uint32_t sample, Counters<STATS> &cnt)
 {
     float4 m0 = tab.mat[3 * idx + 0], m1 = tab.mat[3 * idx + 1];
     V3 color = v3(m0.x, m0.y, m0.z);
 
-    Hit h = finish_hit(tab, idx, p.o, p.d, t, material == kDielectric);
+    Hit h = finish_hit<MIXED>(tab, idx, p.o, p.d, t, material == kDielectric);
     V3 point = p.o + p.d * t;
     V3 n = h.n;
 
@@ -777,14 +827,14 @@ RTX_DEV bool black_surface_ends(const RenderParams &P, const Table &tab, const P
 }
 
 // One whole surface interaction (emission, depth cut, material switch); true = path ended.
-template <bool STATS, bool MANY_LIGHTS>
+template <bool STATS, bool MANY_LIGHTS, bool MIXED = false>
 RTX_DEV bool scatter(const RenderParams &P, const Table &tab, Path &p, int idx, float t,
                      uint32_t pixel, uint32_t sample, Counters<STATS> &cnt)
 {
     if (surface_emission(P, tab, p, idx)) return true;
     if (black_surface_ends(P, tab, p, idx)) return true;
     int material = __float_as_int(tab.mat[3 * idx + 0].w);
-    return bounce<STATS, MANY_LIGHTS>(P, tab, p, idx, t, material, pixel, sample, cnt);
+    return bounce<STATS, MANY_LIGHTS, MIXED>(P, tab, p, idx, t, material, pixel, sample, cnt);
 }
 
 }  // namespace rtx

@@ -181,7 +181,7 @@ RTX_DEV bool wf_finish_path(const RenderParams &P, float4 *rec, uint32_t local, 
 }
 
 // one material's queue: scatter (src/trace.rs:25-68 for that material)
-template <int MATERIAL, bool STATS, bool MANY_LIGHTS, class SHAPE>
+template <int MATERIAL, bool STATS, bool MANY_LIGHTS, class SHAPE, bool MIXED>
 RTX_DEV void wf_shade(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPixels> &L, const Table &tab, uint32_t nxt,
                       Counters<STATS> &cnt, uint32_t *dbg)
 {
@@ -199,7 +199,7 @@ RTX_DEV void wf_shade(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPixels> 
             wf_pixel<SHAPE::kTiles>(P, local, px, py);
             const uint32_t pixel = py * P.width + px;
             WfPath w = wf_load<SHAPE::kPlane>(rec, local);
-            const bool ended = bounce<STATS, MANY_LIGHTS>(P, tab, w.p, w.hit_idx, w.hit_t, MATERIAL, pixel, w.sample, cnt);
+            const bool ended = bounce<STATS, MANY_LIGHTS, MIXED>(P, tab, w.p, w.hit_idx, w.hit_t, MATERIAL, pixel, w.sample, cnt);
             if (ended) {
                 refresh = wf_finish_path<SHAPE::kPlane>(P, rec, local, pixel, w.p.L, w.sample);
             } else {
@@ -537,9 +537,9 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
         __syncthreads();
 
         // ---- shade, one material at a time
-        wf_shade<kDiffuse, STATS, MANY_LIGHTS, SHAPE>(P, rec, L, tab, nxt, cnt, dbg);
-        wf_shade<kMetallic, STATS, MANY_LIGHTS, SHAPE>(P, rec, L, tab, nxt, cnt, dbg);
-        wf_shade<kDielectric, STATS, MANY_LIGHTS, SHAPE>(P, rec, L, tab, nxt, cnt, dbg);
+        wf_shade<kDiffuse, STATS, MANY_LIGHTS, SHAPE, SRC == kSrcBvh>(P, rec, L, tab, nxt, cnt, dbg);
+        wf_shade<kMetallic, STATS, MANY_LIGHTS, SHAPE, SRC == kSrcBvh>(P, rec, L, tab, nxt, cnt, dbg);
+        wf_shade<kDielectric, STATS, MANY_LIGHTS, SHAPE, SRC == kSrcBvh>(P, rec, L, tab, nxt, cnt, dbg);
         __syncthreads();
 
         WF_DBG(D_ITERATIONS, 1u);
