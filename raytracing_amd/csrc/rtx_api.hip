@@ -545,14 +545,6 @@ void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
     // twice as many lanes as still descend, trees of a few hundred objects and more when they do not wait
     // (60 objects: 90.3 against 92.1 ms; 200: 101.1 / 100.4; 10 000: 156.8 / 151.6; 40 000: 152.4 / 144.1)
     P.bvh.leaf_cost = P.bvh.n_nodes >= 128u ? 1u : 2u;
-    {
-        // objects outside the always-tested list are the leaves
-        std::vector<char> listed(n, 0);
-        for (int32_t i : bvh.planes) listed[(size_t)i] = 1;
-        bool all = true;
-        for (size_t i = 0; i < n; ++i) all = all && (listed[i] || is_identity_pose(c->prims[i]));
-        P.bvh.leaves_identity = all ? 1u : 0u;
-    }
 }
 
 // one worker's copy of the block; the worker's device must be current

@@ -29,9 +29,9 @@ RTX_DEV void bvh_try_object(const Table &tab, int pi, V3 o, V3 d, float ray_leng
         else lr = to_local(g, o, d);
         kind = __builtin_amdgcn_readfirstlane(g.kind | ((g.flags & kGeomPow2) << 8));
     } else {
-        // leaves: every lane holds another object; `all_plain` is only passed as true when the
-        // whole scene's leaves have the identity pose
-        if (all_plain) lr = to_local_identity(g, o, d);
+        // leaves: every lane holds another object; `all_plain` = every calling lane's ray is plain.
+        // The rotations are skipped when every object under test has the identity pose.
+        if (all_plain && __ballot(!(g.flags & kGeomIdentity)) == 0ull) lr = to_local_identity(g, o, d);
         else lr = to_local(g, o, d);
     }
     float t;
@@ -202,7 +202,7 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
     const bool all_plain = __ballot(!ray_is_plain(o, d)) == 0ull;
     bvh_always_tested<STATS>(B, tab, o, d, ray_length, all_plain, best, best_t, cnt);
     if (B.n_nodes == 0) return best;
-    const bool leaves_plain = all_plain && B.leaves_identity != 0u;   // wave-uniform
+    const bool leaves_plain = all_plain;   // wave-uniform
 
     const BvhRay R = bvh_ray_setup(B, o, d);
     int sp = 0;

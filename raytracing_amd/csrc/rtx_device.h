@@ -56,7 +56,6 @@ struct BvhView {
     const int32_t *planes; // objects that are tested for every ray
     uint32_t n_nodes, n_planes;
     uint32_t stack_entries;   // postponed nodes a traversal can hold: the tree's depth + 1
-    uint32_t leaves_identity;   // 1: every object in a leaf has the identity pose (kGeomIdentity)
     uint32_t leaf_cost;         // megakernel: lanes at a leaf wait until they outnumber the descending ones this many times
 };
 

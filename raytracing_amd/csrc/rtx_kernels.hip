@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
                 } else {
                     MK_DBG(M_LEAF_ROUNDS, 1u);
                     MK_DBG(M_LEAF_LANES, n_leaf);
-                    const bool leaves_plain = P.bvh.leaves_identity != 0u && __ballot(at_leaf && !plain) == 0ull;
+                    const bool leaves_plain = __ballot(at_leaf && !plain) == 0ull;
                     if (at_leaf) {
                         bvh_try_object<STATS>(tab, ~cur, p.o, p.d, ray_length, best, best_t, cnt, leaves_plain);
                         if (sp > 0) {

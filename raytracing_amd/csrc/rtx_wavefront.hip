@@ -282,7 +282,7 @@ RTX_DEV void wf_extend_bvh(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPix
                 if (cur >= 0) bvh_node_step<STATS, BLOCK>(B, R, best_t, cur, sp, stack, cnt);
             }
         } else if (w_leaf >= w_serve && n_leaf != 0u) {
-            const bool leaves_plain = B.leaves_identity != 0u && __ballot(at_leaf && !plain) == 0ull;
+            const bool leaves_plain = __ballot(at_leaf && !plain) == 0ull;
             WF_DBG(D_LEAF_ROUNDS, 1u);
             WF_DBG(D_LEAF_LANES, n_leaf);
             if (at_leaf) {
