@@ -417,6 +417,7 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
         tab.lights = P.lights;
     }
     if (threadIdx.x < Q_COUNT) L.count[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) L.next = 0u;
     __syncthreads();
 
     const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
@@ -444,16 +445,11 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
     __syncthreads();
 
     for (uint32_t it = 0;; ++it) {
+        // Three barriers per iteration.  Queue counters are reset by thread 0 behind the barrier
+        // that ends their last use and ahead of a barrier that precedes their next one: the two
+        // queues this iteration consumes (they are the next iteration's targets) after the extend
+        // stage, the material queues and the fetch counter after the shade stage.
         const uint32_t cur = it & 1u, nxt = cur ^ 1u;
-        if (threadIdx.x == 0) {
-            L.count[Q_ACTIVE0 + nxt] = 0u;
-            L.count[Q_FRESH0 + nxt] = 0u;
-            L.count[Q_DIFFUSE] = 0u;
-            L.count[Q_METALLIC] = 0u;
-            L.count[Q_DIELECTRIC] = 0u;
-            L.next = 0u;
-        }
-        __syncthreads();
 
         // ---- generate: src/main.rs:17-21
         {
@@ -535,6 +531,10 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
             }
         }
         __syncthreads();
+        if (threadIdx.x == 0) {
+            L.count[Q_ACTIVE0 + cur] = 0u;
+            L.count[Q_FRESH0 + cur] = 0u;
+        }
 
         // ---- shade, one material at a time
         wf_shade<kDiffuse, STATS, MANY_LIGHTS, SHAPE, SRC == kSrcBvh>(P, rec, L, tab, nxt, cnt, dbg);
@@ -544,7 +544,12 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
 
         WF_DBG(D_ITERATIONS, 1u);
         if (L.count[Q_ACTIVE0 + nxt] + L.count[Q_FRESH0 + nxt] == 0u) break;
-        __syncthreads();  // the counters are reset at the top of the next iteration
+        if (threadIdx.x == 0) {
+            L.count[Q_DIFFUSE] = 0u;
+            L.count[Q_METALLIC] = 0u;
+            L.count[Q_DIELECTRIC] = 0u;
+            L.next = 0u;
+        }
     }
 
     if constexpr (STATS) {
