@@ -79,6 +79,7 @@ struct WfLds {
     uint16_t queue[Q_COUNT][PIXELS];
     uint32_t count[Q_COUNT];
     uint32_t next;   // BVH extend stage: rays of the active queue handed out so far
+    uint32_t mcount[2][3];   // linear scan: the material queues' counters, one set per iteration parity
 };
 
 extern __shared__ float4 rtx_smem[];
@@ -95,16 +96,18 @@ enum { D_NODE_ROUNDS = 0, D_NODE_LANES, D_LEAF_ROUNDS, D_LEAF_LANES, D_SERVE_ROU
        D_GEN_ROUNDS, D_GEN_LANES, D_SHADE_ROUNDS, D_SHADE_LANES, D_ITERATIONS, D_COUNT };
 
 // wave64 compaction into an LDS queue: lanes with `pred` append `value`
+// (`counter`: the queue's fill count, L.count[q] unless the caller keeps it elsewhere)
 template <uint32_t PIXELS>
-RTX_DEV void wf_push(WfLds<PIXELS> &L, int q, bool pred, uint32_t value)
+RTX_DEV void wf_push(WfLds<PIXELS> &L, int q, bool pred, uint32_t value, uint32_t *counter = nullptr)
 {
     const unsigned long long mask = __ballot(pred);
     if (mask == 0ull) return;
+    if (counter == nullptr) counter = &L.count[q];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
     const int leader = __builtin_ctzll(mask);
     uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(&L.count[q], (uint32_t)__popcll(mask));
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
     base = __shfl(base, leader, 64);
     if (pred) L.queue[q][base + below] = (uint16_t)value;
 }
@@ -183,9 +186,8 @@ RTX_DEV bool wf_finish_path(const RenderParams &P, float4 *rec, uint32_t local, 
 // one material's queue: scatter (src/trace.rs:25-68 for that material)
 template <int MATERIAL, bool STATS, bool MANY_LIGHTS, class SHAPE, bool MIXED>
 RTX_DEV void wf_shade(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPixels> &L, const Table &tab, uint32_t nxt,
-                      Counters<STATS> &cnt, uint32_t *dbg)
+                      uint32_t count, Counters<STATS> &cnt, uint32_t *dbg)
 {
-    const uint32_t count = L.count[Q_DIFFUSE + MATERIAL];
     for (uint32_t base = 0; base < count; base += SHAPE::kThreads) {
         const uint32_t i = base + threadIdx.x;
         const bool valid = i < count;
@@ -417,6 +419,7 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
         tab.lights = P.lights;
     }
     if (threadIdx.x < Q_COUNT) L.count[threadIdx.x] = 0u;
+    if (threadIdx.x < 6u) L.mcount[threadIdx.x / 3u][threadIdx.x % 3u] = 0u;
     if (threadIdx.x == 0) L.next = 0u;
     __syncthreads();
 
@@ -445,14 +448,21 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
     __syncthreads();
 
     for (uint32_t it = 0;; ++it) {
-        // Three barriers per iteration.  Queue counters are reset by thread 0 behind the barrier
+        // Barriers: one after each stage.  Queue counters are reset by thread 0 behind the barrier
         // that ends their last use and ahead of a barrier that precedes their next one: the two
         // queues this iteration consumes (they are the next iteration's targets) after the extend
-        // stage, the material queues and the fetch counter after the shade stage.
+        // stage; the material queues and the fetch counter after the shade stage (BVH scenes), or,
+        // where extend follows shade without a barrier (linear scan), one set of material counters
+        // per iteration parity, reset while the other set is in use.
         const uint32_t cur = it & 1u, nxt = cur ^ 1u;
+        // Linear scan: no generate stage.  The extend stage takes the fresh queue behind the active
+        // one and generates those paths' camera rays itself: the ray stays in registers, the waves
+        // that do it are full but for one, and an iteration has two barriers instead of three.
+        constexpr bool kMerged = SRC != kSrcBvh;
+        uint32_t *const mcount = L.mcount[cur];
 
         // ---- generate: src/main.rs:17-21
-        {
+        if constexpr (!kMerged) {
             const uint32_t count = L.count[Q_FRESH0 + cur];
             for (uint32_t base = 0; base < count; base += kWfThreads) {
                 const uint32_t i = base + threadIdx.x;
@@ -478,26 +488,47 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
                 }
                 wf_push(L, Q_ACTIVE0 + cur, valid, local);
             }
+            __syncthreads();
         }
-        __syncthreads();
 
         // ---- extend: src/trace.rs:12-23
         if constexpr (SRC == kSrcBvh) {
             wf_extend_bvh<STATS, SHAPE>(P, rec, L, tab, cur, nxt, reinterpret_cast<int32_t *>(rtx_smem + kQueueVec + kRecVec), cnt, dbg);
         } else {
-            const uint32_t count = L.count[Q_ACTIVE0 + cur];
+            const uint32_t n_active = L.count[Q_ACTIVE0 + cur], count = n_active + L.count[Q_FRESH0 + cur];
             for (uint32_t base = 0; base < count; base += kWfThreads) {
                 const uint32_t i = base + threadIdx.x;
                 const bool valid = i < count;
+                const bool fresh = valid && i >= n_active;
                 uint32_t local = 0;
                 int material = -1;
                 bool refresh = false;
+                WfPath w;
+                w.p.o = w.p.d = w.p.T = w.p.L = v3(0.0f, 0.0f, 0.0f);
+                w.p.depth = 0u;
+                w.hit_t = 0.0f;
+                w.hit_idx = -1;
+                w.sample = 0u;
+                uint32_t px = 0, py = 0;
                 if (valid) {
-                    local = L.queue[Q_ACTIVE0 + cur][i];
-                    uint32_t px, py;
+                    local = fresh ? L.queue[Q_FRESH0 + cur][i - n_active] : L.queue[Q_ACTIVE0 + cur][i];
                     wf_pixel<SHAPE::kTiles>(P, local, px, py);
+                }
+                if (__ballot(fresh) != 0ull) {
+                    WF_DBG(D_GEN_ROUNDS, 1u);
+                    WF_DBG(D_GEN_LANES, (uint32_t)__popcll(__ballot(fresh)));
+                    if (fresh) {
+                        // src/main.rs:17-21; the finished path left (0, 0, 0 | next sample index) in the radiance record
+                        w.sample = __float_as_uint(rec[wf_at<SHAPE::kPlane>(local, 3)].w);
+                        uint4 r = draw_block(P, py * P.width + px, w.sample, 0u);
+                        camera_ray(P, px, P.height - 1u - py, u24(r.x), u24(r.y), w.p.o, w.p.d);
+                        w.p.T = v3(1.0f, 1.0f, 1.0f);
+                        cnt.template add<C_SAMPLES>();
+                    }
+                }
+                if (valid) {
                     const uint32_t pixel = py * P.width + px;
-                    WfPath w = wf_load<SHAPE::kPlane>(rec, local);
+                    if (!fresh) w = wf_load<SHAPE::kPlane>(rec, local);
                     Path &p = w.p;
                     cnt.template add<C_RAYS>();
                     float t;
@@ -521,30 +552,32 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
                     } else {
                         wf_store_rad<SHAPE::kPlane>(rec, local, p.L, w.sample);
                         wf_store_ray<SHAPE::kPlane>(rec, local, p, t, idx);
+                        if (fresh) wf_store_thr<SHAPE::kPlane>(rec, local, p);
                         material = __float_as_int(tab.mat[3 * idx + 0].w);
                     }
                 }
                 wf_push(L, Q_FRESH0 + nxt, refresh, local);
-                wf_push(L, Q_DIFFUSE, material == kDiffuse, local);
-                wf_push(L, Q_METALLIC, material == kMetallic, local);
-                wf_push(L, Q_DIELECTRIC, material == kDielectric, local);
+                wf_push(L, Q_DIFFUSE, material == kDiffuse, local, &mcount[kDiffuse]);
+                wf_push(L, Q_METALLIC, material == kMetallic, local, &mcount[kMetallic]);
+                wf_push(L, Q_DIELECTRIC, material == kDielectric, local, &mcount[kDielectric]);
             }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             L.count[Q_ACTIVE0 + cur] = 0u;
             L.count[Q_FRESH0 + cur] = 0u;
+            if constexpr (kMerged) L.mcount[nxt][0] = L.mcount[nxt][1] = L.mcount[nxt][2] = 0u;
         }
 
         // ---- shade, one material at a time
-        wf_shade<kDiffuse, STATS, MANY_LIGHTS, SHAPE, SRC == kSrcBvh>(P, rec, L, tab, nxt, cnt, dbg);
-        wf_shade<kMetallic, STATS, MANY_LIGHTS, SHAPE, SRC == kSrcBvh>(P, rec, L, tab, nxt, cnt, dbg);
-        wf_shade<kDielectric, STATS, MANY_LIGHTS, SHAPE, SRC == kSrcBvh>(P, rec, L, tab, nxt, cnt, dbg);
+        wf_shade<kDiffuse, STATS, MANY_LIGHTS, SHAPE, SRC == kSrcBvh>(P, rec, L, tab, nxt, kMerged ? mcount[kDiffuse] : L.count[Q_DIFFUSE], cnt, dbg);
+        wf_shade<kMetallic, STATS, MANY_LIGHTS, SHAPE, SRC == kSrcBvh>(P, rec, L, tab, nxt, kMerged ? mcount[kMetallic] : L.count[Q_METALLIC], cnt, dbg);
+        wf_shade<kDielectric, STATS, MANY_LIGHTS, SHAPE, SRC == kSrcBvh>(P, rec, L, tab, nxt, kMerged ? mcount[kDielectric] : L.count[Q_DIELECTRIC], cnt, dbg);
         __syncthreads();
 
         WF_DBG(D_ITERATIONS, 1u);
         if (L.count[Q_ACTIVE0 + nxt] + L.count[Q_FRESH0 + nxt] == 0u) break;
-        if (threadIdx.x == 0) {
+        if (!kMerged && threadIdx.x == 0) {
             L.count[Q_DIFFUSE] = 0u;
             L.count[Q_METALLIC] = 0u;
             L.count[Q_DIELECTRIC] = 0u;
