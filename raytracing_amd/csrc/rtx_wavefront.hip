@@ -21,6 +21,8 @@
 // numbers.  One iteration of the in-kernel loop advances every live path of the workgroup by
 // one segment:
 //   generate  fresh queue  -> primary ray of the pixel's next sample -> active queue
+//             (BVH scenes; the linear scan has no such stage: its extend stage takes the fresh
+//             queue behind the active one and makes those camera rays itself)
 //   extend    active queue -> closest hit; a miss or the depth cut finishes the path here
 //                             (-> next fresh queue); others -> the queue of the hit's material
 //   shade<M>  queue M      -> one material at a time: scatter; continuing paths -> next
