@@ -864,7 +864,10 @@ namespace {
 
 // cost-ordered dispatch of the megakernel's tiles: used from this many samples and tiles on
 // (fewer tiles than two per wave slot of the GPU leave nothing to reorder)
-constexpr uint32_t kProbeSamples = 8u, kOrderedMinSamples = 64u, kOrderedMinTiles = 8192u;
+#ifndef RTX_PROBE_SAMPLES
+#define RTX_PROBE_SAMPLES 8u
+#endif
+constexpr uint32_t kProbeSamples = RTX_PROBE_SAMPLES, kOrderedMinSamples = 64u, kOrderedMinTiles = 8192u;
 
 // `no_alloc`: the caller may not allocate device memory -- the tile tables are this GPU's static
 // ones, and whatever would need a fresh block is refused.
