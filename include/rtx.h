@@ -113,8 +113,9 @@ typedef struct rtx_opts {
     /* Several GPUs behind one context.  The loop over sample steps (src/main.rs:14) is cut into
      * n_devices contiguous ranges, GPU g renders range g of every pixel into its own sum buffer on
      * its own stream, and the sums are added as `reduce` says -- all inside rtx_render,
-     * rtx_render_bytes and rtx_progress_*, which keep their signatures.  The image depends on
-     * n_devices only through the order of these n_devices additions per value.
+     * rtx_render_device, rtx_render_bytes and rtx_progress_*, which keep their signatures.  The
+     * image of a one-shot render depends on n_devices only through the order of these n_devices
+     * additions per value (progressive renders: see rtx_progress_*).
      * n_devices 0 or 1: one GPU, `device`.  devices = NULL: ordinals 0 .. n_devices-1.  An ordinal
      * may repeat (several ranges on one GPU; RTX_REDUCE_P2P only).  Entry points that take DEVICE
      * pointers (rtx_render_samples, rtx_accumulate_samples, rtx_divide, rtx_tonemap_bytes) and
@@ -176,8 +177,11 @@ int rtx_render_samples(rtx_ctx *ctx, uint32_t sample_first, uint32_t sample_coun
  * megakernel live in a static device array of RTX_STATIC_MAX_TILES * 8 bytes (2 MiB) that every
  * GPU the library runs on holds until the process ends.  RTX_ERR_UNSUPPORTED for an image of more
  * than RTX_STATIC_MAX_TILES tiles of 8 x 8 pixels (e.g. beyond 4096 x 4096) and for the wavefront
- * variant on a scene whose BVH is deep (its path state is then a device block).  All contexts on one GPU share that
- * GPU's array: calls that overlap in time on one GPU race, whatever their streams. */
+ * variant on a scene whose BVH is deep (its path state is then a device block), and on a context
+ * with collect_stats = 1 (reading counters back waits for the stream).  The call records no timing
+ * events, so rtx_last_kernel_ms does not cover it; nothing it does is illegal on a capturing stream.
+ * All contexts on one GPU share that GPU's array: calls that overlap in time on one GPU race,
+ * whatever their streams -- replays of graphs that hold such a call included. */
 #define RTX_STATIC_MAX_TILES 262144u
 int rtx_render_samples_static(rtx_ctx *ctx, uint32_t sample_first, uint32_t sample_count,
                               float *d_sum, void *hip_stream);
@@ -203,6 +207,15 @@ int rtx_divide(rtx_ctx *ctx, float *d_rgb, uint64_t n_floats, float divisor, voi
 int rtx_tonemap_bytes(rtx_ctx *ctx, const float *d_sum, uint64_t n_floats, float divisor,
                       uint8_t *d_bytes, void *hip_stream);
 
+/* rtx_render (src/main.rs:13-31) with the image left on the device: renders n_samples samples per
+ * pixel of the scene given to rtx_set_scene and writes the mean linear radiance to d_rgb, a DEVICE
+ * buffer of width*height*3 floats (row 0 = top) on the context's first GPU, which the caller has
+ * finished writing to.  A multi-GPU context splits the samples, and GPU g adds slice g of all sums,
+ * divides and writes that slice straight into d_rgb (peer access), or -- RTX_REDUCE_RCCL -- the
+ * first GPU copies the all-reduced image there.  Same bits as rtx_render.  Returns when the image
+ * is complete. */
+int rtx_render_device(rtx_ctx *ctx, uint32_t n_samples, float *d_rgb);
+
 /* render + color_correction + the byte conversion of write (src/main.rs:38-41) without
  * the float image leaving the device: bytes = width*height*3 values of the PPM body
  * (host memory, row 0 = top). */
@@ -216,15 +229,20 @@ int rtx_render_bytes(rtx_ctx *ctx, const rtx_scene *scene, uint8_t *bytes);
  *   step:  render the next sample_count samples onto the sum; returns when done.
  *   read:  any of rgb_mean (sum / samples, what rtx_render returns), sum (the state to
  *          save), bytes (tone-mapped, as rtx_render_bytes) and samples_done may be NULL.
- * After begin + steps totalling n samples, read returns the bits of rtx_render with
- * n_samples = n, however the steps were cut and wherever a save / resume happened.
- * rtx_render and rtx_render_bytes on the same context end the progressive render. */
+ * On a single-GPU context, after begin + steps totalling n samples, read returns the bits of
+ * rtx_render with n_samples = n, however the steps were cut and wherever a save / resume happened.
+ * On a multi-GPU context every step is split over the GPUs again and a resumed sum continues on
+ * the first one, so the order of a value's additions -- and with it the last bits of the result
+ * (<= 1e-6 relative) -- depends on the step cuts.  read adds the GPUs' sums once, whatever
+ * combination of outputs is asked for.
+ * rtx_render, rtx_render_device and rtx_render_bytes on the same context end the progressive render. */
 int rtx_progress_begin(rtx_ctx *ctx, const rtx_scene *scene, const float *sum, uint32_t samples_done);
 int rtx_progress_step(rtx_ctx *ctx, uint32_t sample_count);
 int rtx_progress_read(rtx_ctx *ctx, float *rgb_mean, float *sum, uint8_t *bytes, uint32_t *samples_done);
 
 /* Deterministic primary-visibility pass: one ray through every pixel centre
- * (src/main.rs:19-21 with du = dv = 0.5) and its closest hit (src/trace.rs:102-121).
+ * (src/main.rs:19-21 with du = dv = 0.5) and its closest hit (src/trace.rs:102-121), on the
+ * context's first GPU.
  * Host output arrays of width*height entries (normal: *3), row 0 = top; any may
  * be NULL.  hit_id = object index or -1. */
 int rtx_primary(rtx_ctx *ctx, const rtx_scene *scene, int32_t *hit_id, float *t,
@@ -249,7 +267,7 @@ const char *rtx_last_error(void);
 
 /* ABI version of this header: bumped on any layout or signature change. */
 uint32_t rtx_abi_version(void);
-#define RTX_ABI_VERSION 3u
+#define RTX_ABI_VERSION 4u
 
 #ifdef __cplusplus
 }

@@ -8,7 +8,7 @@
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTX_ABI_VERSION: u32 = 3;
+pub const RTX_ABI_VERSION: u32 = 4;
 
 pub const RTX_OK: c_int = 0;
 pub const RTX_ERR_INVALID_ARG: c_int = -1;
@@ -118,6 +118,7 @@ extern "C" {
     pub fn rtx_destroy(ctx: *mut rtx_ctx);
     pub fn rtx_set_scene(ctx: *mut rtx_ctx, scene: *const rtx_scene) -> c_int;
     pub fn rtx_render(ctx: *mut rtx_ctx, scene: *const rtx_scene, rgb: *mut f32) -> c_int;
+    pub fn rtx_render_device(ctx: *mut rtx_ctx, n_samples: u32, d_rgb: *mut f32) -> c_int;
     pub fn rtx_render_samples(ctx: *mut rtx_ctx, sample_first: u32, sample_count: u32, d_sum: *mut f32, hip_stream: *mut c_void) -> c_int;
     pub fn rtx_render_samples_static(ctx: *mut rtx_ctx, sample_first: u32, sample_count: u32, d_sum: *mut f32, hip_stream: *mut c_void) -> c_int;
     pub fn rtx_accumulate_samples(ctx: *mut rtx_ctx, sample_first: u32, sample_count: u32, d_sum: *mut f32, hip_stream: *mut c_void) -> c_int;

@@ -213,6 +213,8 @@ struct rtx_ctx {
     float *d_reduced = nullptr;     // P2P: this worker's slice of the summed image; RCCL: the whole of it
     size_t d_reduced_floats = 0;
     void *comm = nullptr;           // RCCL communicator rank of this worker
+    void *h_stage = nullptr;        // pinned host block this worker's part of an image passes through on its way out
+    size_t h_stage_bytes = 0;
 };
 
 namespace {
@@ -596,6 +598,19 @@ int ensure_bytes(rtx_ctx *c, size_t n)
     return RTX_OK;
 }
 
+// Pinned staging for the delivery to caller memory: copies from N GPUs into pageable memory are
+// staged by the runtime one after the other, copies into pinned blocks run side by side.
+int ensure_stage(rtx_ctx *c, size_t bytes)
+{
+    if (c->h_stage_bytes >= bytes) return RTX_OK;
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    c->h_stage = nullptr;
+    c->h_stage_bytes = 0;
+    HIP_TRY(hipHostMalloc(&c->h_stage, bytes, hipHostMallocPortable));
+    c->h_stage_bytes = bytes;
+    return RTX_OK;
+}
+
 int ensure_reduced(rtx_ctx *c, size_t floats)
 {
     if (c->d_reduced_floats >= floats) return RTX_OK;
@@ -705,6 +720,7 @@ void destroy_worker(rtx_ctx *c)
     if (c->d_bytes) (void)hipFree(c->d_bytes);
     if (c->d_primary) (void)hipFree(c->d_primary);
     if (c->d_reduced) (void)hipFree(c->d_reduced);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->d_wavefront) (void)hipFree(c->d_wavefront);
     if (c->d_tiles) (void)hipFree(c->d_tiles);
     if (c->d_stats) (void)hipFree(c->d_stats);
@@ -868,6 +884,8 @@ namespace {
 #define RTX_PROBE_SAMPLES 8u
 #endif
 constexpr uint32_t kProbeSamples = RTX_PROBE_SAMPLES, kOrderedMinSamples = 64u, kOrderedMinTiles = 8192u;
+// the launch that follows the probe renders sample_count - kProbeSamples samples: at least one
+static_assert(kProbeSamples >= 1u && kProbeSamples < kOrderedMinSamples, "the probe must leave samples for the ordered launch");
 
 // `no_alloc`: the caller may not allocate device memory -- the tile tables are this GPU's static
 // ones, and whatever would need a fresh block is refused.
@@ -890,15 +908,22 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
     P.stats = stats ? c->d_stats : nullptr;
     c->stats_valid = false;
     const uint32_t n_tiles = ((P.width + 7u) / 8u) * ((P.height + 7u) / 8u);
+    // A call that may sit under HIP graph capture records no timing events (an event recorded into a
+    // capturing stream cannot be waited for or read) and reads no counters back (a copy to the host
+    // followed by a wait is illegal there): rtx_last_kernel_ms and rtx_get_stats do not cover it.
+    if (no_alloc && stats)
+        return fail(RTX_ERR_UNSUPPORTED, "rtx_render_samples_static: not available on a context with collect_stats = 1");
+    const bool timed = !no_alloc;
+    c->timed = false;
     if (P.ray_depth == 0u) {
         // src/trace.rs:12-14: the camera ray itself is cut, nothing is intersected
-        HIP_TRY(hipEventRecord(c->ev_start, stream));
+        if (timed) HIP_TRY(hipEventRecord(c->ev_start, stream));
         const uint64_t n = (uint64_t)P.width * P.height * 3u;
         hipLaunchKernelGGL(k_add_zero_samples, dim3((uint32_t)std::min<uint64_t>((n + 255u) / 256u, 4096u)), dim3(256), 0,
                            stream, d_sum, n, accumulate ? 1 : 0, sample_count > 0u ? 1 : 0);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(c->ev_stop, stream));
-        c->timed = true;
+        if (timed) HIP_TRY(hipEventRecord(c->ev_stop, stream));
+        c->timed = timed;
         if (stats) {
             std::memset(&c->stats, 0, sizeof(c->stats));
             c->stats.samples = (uint64_t)P.width * P.height * sample_count;
@@ -915,7 +940,7 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
                         P.width, P.height, n_tiles, (unsigned)RTX_STATIC_MAX_TILES);
     }
     if (stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, rtx::C_COUNT * sizeof(unsigned long long), stream));
-    HIP_TRY(hipEventRecord(c->ev_start, stream));
+    if (timed) HIP_TRY(hipEventRecord(c->ev_start, stream));
     if (c->opts.mode == RTX_MODE_WAVEFRONT) {
         rtx::WfState S;
         S.rec = nullptr;
@@ -972,8 +997,8 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
         }
         HIP_TRY(rtx::launch_megakernel(P, c->src, stats, c->pool_limit, stream));
     }
-    HIP_TRY(hipEventRecord(c->ev_stop, stream));
-    c->timed = true;
+    if (timed) HIP_TRY(hipEventRecord(c->ev_stop, stream));
+    c->timed = timed;
     if (stats) {
         unsigned long long v[rtx::C_COUNT];
         HIP_TRY(hipMemcpyAsync(v, c->d_stats, sizeof(v), hipMemcpyDeviceToHost, stream));
@@ -1008,14 +1033,45 @@ int render_shares(rtx_ctx *c, uint32_t first, uint32_t count, bool accumulate)
     return RTX_OK;
 }
 
-// Adds the workers' d_image buffers and delivers the result to host memory: the mean (divide) or
-// the plain sum as floats, and / or the tone-mapped bytes of sum / divisor.  The workers' own sums
-// stay as they are, so a progressive render can go on.
-int reduce_to_host(rtx_ctx *c, float divisor, bool divide, float *host_floats, uint8_t *host_bytes)
+// Where the added-up image of a multi-GPU context goes.  Any subset may be asked for at once: the
+// sums are added once whatever is delivered.
+struct Delivery {
+    float *host_sum = nullptr;     // the plain sum (the state a progressive render saves)
+    float *host_mean = nullptr;    // sum / divisor
+    uint8_t *host_bytes = nullptr; // sum / divisor, tone-mapped
+    float *dev_mean = nullptr;     // sum / divisor in a device buffer on the context's first GPU
+};
+
+// one worker's part [first, first + len) of the image, from its pinned block into the caller's memory
+void hand_over(const rtx_ctx *w, const Delivery &D, uint64_t first, uint64_t len, float divisor)
+{
+    const unsigned char *stage = static_cast<const unsigned char *>(w->h_stage);
+    if (D.host_sum || D.host_mean) {
+        const float *v = reinterpret_cast<const float *>(stage);
+        if (D.host_sum) std::memcpy(D.host_sum + first, v, len * sizeof(float));
+        // when the sum is delivered too it is what left the device, and the mean is the same IEEE
+        // division done here
+        if (D.host_mean && D.host_sum)
+            for (uint64_t i = 0; i < len; ++i) D.host_mean[first + i] = v[i] / divisor;
+        else if (D.host_mean) std::memcpy(D.host_mean + first, v, len * sizeof(float));
+    }
+    if (D.host_bytes) {
+        const size_t off = (D.host_sum || D.host_mean) ? align16(len * sizeof(float)) : 0u;
+        std::memcpy(D.host_bytes + first, stage + off, len);
+    }
+}
+
+// Adds the workers' d_image buffers and delivers the result.  The workers' own sums stay as they
+// are, so a progressive render can go on.  Returns when everything asked for has arrived.
+int reduce_deliver(rtx_ctx *c, float divisor, const Delivery &D)
 {
     std::vector<rtx_ctx *> ws = workers_of(c);
     const uint32_t G = (uint32_t)ws.size();
     const uint64_t floats = (uint64_t)c->scene.width * c->scene.height * 3u;
+    const bool want_floats = D.host_sum || D.host_mean;
+    // the device divides unless the plain sum has to leave it
+    const bool dev_divides = !D.host_sum && (D.host_mean || D.dev_mean);
+    if (D.host_sum && D.dev_mean) return fail(RTX_ERR_INVALID_ARG, "the plain sum and a device image cannot be delivered together");
     if (c->opts.reduce == RTX_REDUCE_RCCL) {
         for (rtx_ctx *w : ws) {
             DeviceGuard dg(w->device);
@@ -1033,22 +1089,29 @@ int reduce_to_host(rtx_ctx *c, float divisor, bool divide, float *host_floats, u
             }
         }
         RCCL_TRY(g_rccl.GroupEnd());
-        // every GPU now holds the sum; GPU 0 finishes it and sends it to the host
+        // every GPU now holds the sum; GPU 0 finishes it and sends it on
         DeviceGuard dg(c->device);
-        if (host_bytes) {
+        const size_t float_bytes = want_floats ? align16(floats * sizeof(float)) : 0u;
+        if (want_floats || D.host_bytes) {
+            int rc = ensure_stage(c, float_bytes + (D.host_bytes ? floats : 0u));
+            if (rc != RTX_OK) return rc;
+        }
+        unsigned char *stage = static_cast<unsigned char *>(c->h_stage);
+        if (D.host_bytes) {
             int rc = ensure_bytes(c, floats);
             if (rc != RTX_OK) return rc;
             HIP_TRY(rtx::launch_tonemap(c->d_reduced, floats, divisor, c->d_bytes, c->stream));
-            HIP_TRY(hipMemcpyAsync(host_bytes, c->d_bytes, floats, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipMemcpyAsync(stage + float_bytes, c->d_bytes, floats, hipMemcpyDeviceToHost, c->stream));
         }
-        if (host_floats) {
-            if (divide) HIP_TRY(rtx::launch_divide(c->d_reduced, floats, divisor, c->stream));
-            HIP_TRY(hipMemcpyAsync(host_floats, c->d_reduced, floats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-        }
+        if (dev_divides) HIP_TRY(rtx::launch_divide(c->d_reduced, floats, divisor, c->stream));
+        if (want_floats) HIP_TRY(hipMemcpyAsync(stage, c->d_reduced, floats * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+        if (D.dev_mean)
+            HIP_TRY(hipMemcpyAsync(D.dev_mean, c->d_reduced, floats * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
         for (rtx_ctx *w : ws) {
             DeviceGuard wg(w->device);
             HIP_TRY(hipStreamSynchronize(w->stream));
         }
+        hand_over(c, D, 0u, floats, divisor);
         return RTX_OK;
     }
     ReduceSources S;
@@ -1062,29 +1125,43 @@ int reduce_to_host(rtx_ctx *c, float divisor, bool divide, float *host_floats, u
         if (len == 0) continue;
         DeviceGuard dg(w->device);
         if (!dg.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", w->device);
-        int rc = ensure_reduced(w, len);
+        // a device image alone: every GPU writes its slice straight into it (over peer access)
+        const bool direct = D.dev_mean && !want_floats && !D.host_bytes;
+        int rc = direct ? RTX_OK : ensure_reduced(w, len);
         if (rc != RTX_OK) return rc;
+        const size_t float_bytes = want_floats ? align16(len * sizeof(float)) : 0u;
+        if (want_floats || D.host_bytes) {
+            rc = ensure_stage(w, float_bytes + (D.host_bytes ? len : 0u));
+            if (rc != RTX_OK) return rc;
+        }
+        unsigned char *stage = static_cast<unsigned char *>(w->h_stage);
         // the slice is complete once every worker's share is
         for (rtx_ctx *o : ws)
             if (o != w) HIP_TRY(hipStreamWaitEvent(w->stream, o->ev_done, 0));
         const uint32_t blocks = (uint32_t)std::min<uint64_t>((len / 4u + 255u) / 256u + 1u, 2048u);
-        const bool div_now = divide && !host_bytes;
-        hipLaunchKernelGGL(k_reduce_slices, dim3(blocks), dim3(256), 0, w->stream, S, first, len, divisor, div_now ? 1 : 0,
-                           w->d_reduced);
+        const bool div_now = dev_divides && !D.host_bytes;
+        float *out = direct ? D.dev_mean + first : w->d_reduced;
+        hipLaunchKernelGGL(k_reduce_slices, dim3(blocks), dim3(256), 0, w->stream, S, first, len, divisor, div_now ? 1 : 0, out);
         HIP_TRY(hipGetLastError());
-        if (host_bytes) {
+        if (D.host_bytes) {
             rc = ensure_bytes(w, len);
             if (rc != RTX_OK) return rc;
             HIP_TRY(rtx::launch_tonemap(w->d_reduced, len, divisor, w->d_bytes, w->stream));
-            HIP_TRY(hipMemcpyAsync(host_bytes + first, w->d_bytes, len, hipMemcpyDeviceToHost, w->stream));
-            if (host_floats && divide) HIP_TRY(rtx::launch_divide(w->d_reduced, len, divisor, w->stream));
+            HIP_TRY(hipMemcpyAsync(stage + float_bytes, w->d_bytes, len, hipMemcpyDeviceToHost, w->stream));
+            if (dev_divides) HIP_TRY(rtx::launch_divide(w->d_reduced, len, divisor, w->stream));
         }
-        if (host_floats)
-            HIP_TRY(hipMemcpyAsync(host_floats + first, w->d_reduced, len * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+        if (want_floats) HIP_TRY(hipMemcpyAsync(stage, w->d_reduced, len * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+        if (D.dev_mean && !direct)
+            HIP_TRY(hipMemcpyAsync(D.dev_mean + first, w->d_reduced, len * sizeof(float), hipMemcpyDeviceToDevice, w->stream));
     }
-    for (rtx_ctx *w : ws) {
+    // the GPUs copy side by side; each part is handed over as soon as it has arrived
+    for (uint32_t g = 0; g < G; ++g) {
+        rtx_ctx *w = ws[g];
         DeviceGuard dg(w->device);
         HIP_TRY(hipStreamSynchronize(w->stream));
+        uint64_t first, len;
+        image_slice(floats, G, g, first, len);
+        if (len != 0) hand_over(w, D, first, len, divisor);
     }
     return RTX_OK;
 }
@@ -1161,7 +1238,11 @@ int rtx_render(rtx_ctx *c, const rtx_scene *s, float *rgb)
         if (is_multi(c)) {
             // one call from the host does everything (src/main.rs:38): split, render, add, divide
             rc = render_shares(c, 0, s->n_samples, false);
-            if (rc == RTX_OK) rc = reduce_to_host(c, (float)s->n_samples, true, rgb, nullptr);
+            if (rc == RTX_OK) {
+                Delivery D;
+                D.host_mean = rgb;
+                rc = reduce_deliver(c, (float)s->n_samples, D);
+            }
             gather_stats(c);
             return rc;
         }
@@ -1173,6 +1254,40 @@ int rtx_render(rtx_ctx *c, const rtx_scene *s, float *rgb)
         if (rc != RTX_OK) return rc;
         HIP_TRY(hipMemcpy(rgb, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
         return RTX_OK;
+    });
+}
+
+int rtx_render_device(rtx_ctx *c, uint32_t n_samples, float *d_rgb)
+{
+    if (!c || !d_rgb) return fail(RTX_ERR_INVALID_ARG, "rtx_render_device: null argument");
+    if (!c->have_scene) return fail(RTX_ERR_NO_SCENE, "rtx_set_scene has not been called");
+    return guarded("rtx_render_device", [&]() -> int {
+        DeviceGuard g(c->device);
+        if (!g.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", c->device);
+        const size_t floats = (size_t)c->scene.width * c->scene.height * 3u;
+        c->progress_active = false;
+        hipStream_t own = c->stream;   // a multi-GPU context's first worker has its own stream
+        if (n_samples == 0) {
+            // src/main.rs:14: zero iterations leave the zero-initialised image (src/image.rs:17)
+            HIP_TRY(hipMemsetAsync(d_rgb, 0, floats * sizeof(float), own));
+            HIP_TRY(hipStreamSynchronize(own));
+            return RTX_OK;
+        }
+        int rc;
+        if (is_multi(c)) {
+            rc = render_shares(c, 0, n_samples, false);
+            if (rc == RTX_OK) {
+                Delivery D;
+                D.dev_mean = d_rgb;
+                rc = reduce_deliver(c, (float)n_samples, D);
+            }
+            gather_stats(c);
+            return rc;
+        }
+        rc = render_range(c, 0, n_samples, d_rgb, nullptr, false);
+        if (rc == RTX_OK) rc = rtx_divide(c, d_rgb, floats, (float)n_samples, nullptr);
+        if (rc == RTX_OK) HIP_TRY(hipStreamSynchronize(nullptr));
+        return rc;
     });
 }
 
@@ -1189,7 +1304,11 @@ int rtx_render_bytes(rtx_ctx *c, const rtx_scene *s, uint8_t *bytes)
         const float divisor = s->n_samples == 0 ? 1.0f : (float)s->n_samples;
         if (is_multi(c)) {
             rc = render_shares(c, 0, s->n_samples, false);
-            if (rc == RTX_OK) rc = reduce_to_host(c, divisor, true, nullptr, bytes);
+            if (rc == RTX_OK) {
+                Delivery D;
+                D.host_bytes = bytes;
+                rc = reduce_deliver(c, divisor, D);
+            }
             gather_stats(c);
             return rc;
         }
@@ -1270,10 +1389,12 @@ int rtx_progress_read(rtx_ctx *c, float *rgb_mean, float *sum, uint8_t *bytes, u
         const float divisor = c->progress_done == 0 ? 1.0f : (float)c->progress_done;
         if (is_multi(c)) {
             // the state to save is the added-up sum: a resume puts it on the first GPU
-            int rc = RTX_OK;
-            if (sum) rc = reduce_to_host(c, 1.0f, false, sum, nullptr);
-            if (rc == RTX_OK && (rgb_mean || bytes)) rc = reduce_to_host(c, divisor, true, rgb_mean, bytes);
-            return rc;
+            if (!sum && !rgb_mean && !bytes) return RTX_OK;
+            Delivery D;
+            D.host_sum = sum;
+            D.host_mean = rgb_mean;
+            D.host_bytes = bytes;
+            return reduce_deliver(c, divisor, D);   // one pass over the GPUs' sums whatever is asked for
         }
         if (sum) HIP_TRY(hipMemcpy(sum, c->d_image, floats * sizeof(float), hipMemcpyDeviceToHost));
         if (bytes) {
@@ -1297,7 +1418,9 @@ int rtx_primary(rtx_ctx *c, const rtx_scene *s, int32_t *hit_id, float *t, float
     if (!c) return fail(RTX_ERR_INVALID_ARG, "ctx is null");
     int rc = rtx_set_scene(c, s);
     if (rc != RTX_OK) return rc;
-    DeviceGuard g(c->device);
+    return guarded("rtx_primary", [&]() -> int {
+    DeviceGuard g(c->device);   // a multi-GPU context runs this pass on its first GPU
+    if (!g.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", c->device);
     const size_t n = (size_t)s->width * s->height;
     // one device block, kept by the context: ids | t | normal | inside
     const size_t bytes = n * 4 + n * 4 + n * 12 + align16(n);
@@ -1322,6 +1445,7 @@ int rtx_primary(rtx_ctx *c, const rtx_scene *s, int32_t *hit_id, float *t, float
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) return fail(RTX_ERR_DEVICE, "primary pass: %s", hipGetErrorString(e));
     return RTX_OK;
+    });
 }
 
 int rtx_get_stats(rtx_ctx *c, rtx_stats *out)

@@ -47,3 +47,59 @@ def algorithmic_flops(stats: dict, bvh_node_tests: int = 0) -> int:
 PEAK_FP32_VECTOR_TFLOPS = 157.3
 # one non-packed FMA per lane per clock
 PEAK_FP32_NONPACKED_TFLOPS = 78.6
+
+
+def _identity_pose(p) -> bool:
+    return tuple(float(x) for x in p.rotation) == (0.0, 0.0, 0.0, 1.0)
+
+
+def elided_flops(stats: dict, scene, bvh: bool) -> int:
+    """The part of algorithmic_flops() the kernels provably never execute, because an exact
+    shortcut returns the same bits without the arithmetic the constants above credit:
+
+    * the two quaternion rotations of the world -> local map (60 of TO_LOCAL's 63) for an object
+      in the identity pose: every object test of a linear scan (all rays of a tame scene are
+      "plain"), and the tests of the always-tested planes of a BVH scene.  BVH leaf tests skip
+      them only when all 64 lanes hold identity-pose objects, which is not counted;
+    * colour / pi (3 divisions per diffuse bounce), divided once at upload;
+    * for a light that is a box in the identity pose, per light intersection: the two rotations
+      (60) and, when it hits, the rotation and normalisation of its normal (39), replaced by
+      |n . d| = |d_k|.
+    Power-of-two radii turn divisions into as many multiplications, which is not an elision.
+    """
+    from . import _abi
+    per_kind_identity = [0, 0, 0]
+    per_kind = [0, 0, 0]
+    for p in scene.prims:
+        per_kind[p.kind] += 1
+        if _identity_pose(p):
+            per_kind_identity[p.kind] += 1
+    f = 0
+    for k in range(3):
+        if per_kind[k] == 0 or (bvh and k != _abi.PLANE):
+            continue
+        # tests are spread evenly over the objects of a kind (every ray tests every scanned object)
+        f += stats["prim_tests"][k] * per_kind_identity[k] // per_kind[k] * 60
+    f += stats["diffuse_bounces"] * 3
+    lights = scene.light_indices()
+    if lights and all(scene.prims[i].kind == _abi.BOX and _identity_pose(scene.prims[i]) for i in lights):
+        tests = sum(stats["light_tests"])
+        hits = stats["light_pdf"][1] + 2 * stats["light_pdf"][2]
+        f += tests * 60 + hits * 39
+    return int(f)
+
+
+def executed_flops(pmc: dict):
+    """FP32 operations the lanes actually executed in one profiled step, from the rocprofv3
+    counters of that step (wave-level instruction counts by class): (ADD + MUL + TRANS + 2 FMA)
+    x 64 lanes x the thread-active fraction of the step's VALU instructions.  A packed instruction
+    (v_pk_fma_f32, v_pk_mul_f32: two operations per lane) is counted once by its class counter,
+    so the figure is a lower bound by the packed share (about 8 % of the static VALU count of the
+    reference scene's kernel).  None when the counters are missing."""
+    need = ("SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32",
+            "thread_active_fraction")
+    if not pmc or any(k not in pmc for k in need):
+        return None
+    ops = (pmc["SQ_INSTS_VALU_ADD_F32"] + pmc["SQ_INSTS_VALU_MUL_F32"] + pmc["SQ_INSTS_VALU_TRANS_F32"]
+           + 2.0 * pmc["SQ_INSTS_VALU_FMA_F32"])
+    return ops * 64.0 * pmc["thread_active_fraction"]

@@ -27,6 +27,7 @@ SYMBOLS = {
     "rtx_destroy": (None, [C.c_void_p]),
     "rtx_set_scene": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene)]),
     "rtx_render": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene), _FP]),
+    "rtx_render_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "rtx_render_samples": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rtx_render_samples_static": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rtx_accumulate_samples": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
@@ -148,6 +149,11 @@ class Renderer:
         self._scene = scene
         return out
 
+    def render_device(self, n_samples: int, d_rgb_ptr: int):
+        """render() of the scene given to set_scene with the mean image left in a device buffer on
+        the context's first GPU (raw pointer); all of the context's GPUs take part."""
+        _check(self._lib.rtx_render_device(self._ctx, n_samples, C.c_void_p(d_rgb_ptr)))
+
     # -- device-resident pieces (multi-GPU, benchmarks) -------------------
     def render_samples(self, sample_first: int, sample_count: int, d_sum_ptr: int, stream: int = 0):
         """Sum of samples [first, first+count) into a device buffer (raw pointer)."""
@@ -206,6 +212,18 @@ class Renderer:
             args = (out.ctypes.data_as(_FP), None) if what == "mean" else (None, out.ctypes.data_as(_FP))
             _check(self._lib.rtx_progress_read(self._ctx, args[0], args[1], None, C.byref(done)))
         return out, done.value
+
+    def progress_read_all(self):
+        """mean, sum and bytes from ONE rtx_progress_read call: (mean, sum, bytes, samples_done)."""
+        sc = self._scene
+        done = C.c_uint32()
+        shape = (sc.height, sc.width, 3)
+        mean = np.empty(shape, dtype=np.float32)
+        total = np.empty(shape, dtype=np.float32)
+        data = np.empty(shape, dtype=np.uint8)
+        _check(self._lib.rtx_progress_read(self._ctx, mean.ctypes.data_as(_FP), total.ctypes.data_as(_FP),
+                                           data.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(done)))
+        return mean, total, data, done.value
 
     def divide(self, d_ptr: int, n_floats: int, divisor: float, stream: int = 0):
         _check(self._lib.rtx_divide(self._ctx, C.c_void_p(d_ptr), n_floats, divisor, C.c_void_p(stream)))

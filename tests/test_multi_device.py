@@ -105,6 +105,61 @@ def test_bytes_progressive_and_statistics_across_devices(oracle):
     assert err.max() <= 1e-6
 
 
+def test_progress_read_of_everything_at_once_and_the_image_left_on_the_device(oracle):
+    """One rtx_progress_read for mean, sum and bytes adds the GPUs' sums once and returns what three
+    separate reads return; rtx_render_device leaves the bits of rtx_render in a device buffer."""
+    import torch
+    sc = dielectric_scene(width=75, height=41, n_samples=9, ray_depth=8)
+    for opts in (dict(devices=[0, 0, 0]), dict(devices=[0], reduce=_abi.REDUCE_RCCL), dict()):
+        with Renderer(seed=4, **opts) as r:
+            want = r.render(sc)
+            r.progress_begin(sc)
+            r.progress_step(4)
+            r.progress_step(5)
+            m1, _ = r.progress_read("mean")
+            s1, _ = r.progress_read("sum")
+            b1, _ = r.progress_read("bytes")
+            m, s, b, done = r.progress_read_all()
+            assert done == 9
+            assert np.array_equal(m.view(np.uint32), m1.view(np.uint32))
+            assert np.array_equal(s.view(np.uint32), s1.view(np.uint32))
+            assert np.array_equal(b, b1)
+            assert np.array_equal((s / np.float32(9)).view(np.uint32), m.view(np.uint32))
+            # the image left on the device
+            buf = torch.full((sc.width * sc.height * 3,), float("nan"), dtype=torch.float32, device="cuda")
+            torch.cuda.synchronize()
+            r.set_scene(sc)
+            r.render_device(sc.n_samples, buf.data_ptr())
+            got = buf.cpu().numpy().reshape(want.shape)
+            assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+            r.render_device(0, buf.data_ptr())
+            assert not buf.cpu().numpy().any()
+            if opts:
+                assert r.last_kernel_ms() >= 0.0
+
+
+def test_distinct_gpus_both_reduces(oracle):
+    """Two different GPUs: peer access, the slice reduce over it, and RCCL with two ranks.  Skipped on a
+    one-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    sc = dielectric_scene(width=75, height=41, n_samples=11, ray_depth=8)
+    want = oracle_split_mean(oracle, sc, 5, 2)
+    for reduce in (_abi.REDUCE_P2P, _abi.REDUCE_RCCL):
+        with Renderer(seed=5, devices=[0, 1], reduce=reduce) as r:
+            got = r.render(sc)
+            buf = torch.full((sc.width * sc.height * 3,), float("nan"), dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()
+            r.render_device(sc.n_samples, buf.data_ptr())
+            dev = buf.cpu().numpy().reshape(got.shape)
+            data = r.render_bytes(sc)
+        assert np.array_equal(got.view(np.uint32), dev.view(np.uint32))
+        assert data.shape == got.shape
+        # a sum of two terms is the same addition whoever adds: both reduces give the oracle's bits
+        assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+
+
 def test_full_hd_frame_split_in_two(oracle):
     """The slice reduce at a real size: 1920 x 1080, two workers, against the unsplit render."""
     sc = reference_scene(width=1920, height=1080, n_samples=4)
