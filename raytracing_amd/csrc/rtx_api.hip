@@ -24,7 +24,7 @@
 // allocate: one copy per GPU, held until the process ends.  Host code never uses this name as an
 // address (it is a host-side stand-in): rtx_create asks the runtime for the device address, once
 // per context with the context's device current, and everything else goes through that pointer.
-static __device__ __align__(256) uint32_t scratch[2u * RTX_STATIC_MAX_TILES];
+static __device__ __align__(256) uint32_t scratch[3u * RTX_STATIC_MAX_TILES + 64u];
 
 namespace {
 
@@ -884,6 +884,17 @@ namespace {
 #define RTX_PROBE_SAMPLES 8u
 #endif
 constexpr uint32_t kProbeSamples = RTX_PROBE_SAMPLES, kOrderedMinSamples = 64u, kOrderedMinTiles = 8192u;
+#ifndef RTX_CHUNK_MIN
+#define RTX_CHUNK_MIN 16u
+#endif
+#ifndef RTX_CHUNK_MIN_ONE
+#define RTX_CHUNK_MIN_ONE 32u
+#endif
+#ifndef RTX_CHUNK_MAX
+#define RTX_CHUNK_MAX 6u
+#endif
+// work queue: fewest samples of a chunk (two-pixel kernel, one-pixel kernels), most chunks (1: no queue)
+constexpr uint32_t kChunkMin = RTX_CHUNK_MIN, kChunkMinOnePixel = RTX_CHUNK_MIN_ONE, kChunkMax = RTX_CHUNK_MAX;
 // the launch that follows the probe renders sample_count - kProbeSamples samples: at least one
 static_assert(kProbeSamples >= 1u && kProbeSamples < kOrderedMinSamples, "the probe must leave samples for the ordered launch");
 
@@ -957,11 +968,12 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
         }
         HIP_TRY(rtx::launch_wavefront(P, S, c->src, stats, stream));
     } else {
-        // Waves run one tile each and the launch ends when the last of them does; with tiles
-        // handed out in image order the last ones started can be the long ones.  A first launch
-        // of kProbeSamples samples records what each tile costs, the rest of the samples are
-        // continued on top of its sums with the tiles dispatched longest first.  The split
-        // changes no bits (the sums continue in sample order, as rtx_accumulate_samples does).
+        // A wave runs one unit (a tile or two) and the launch ends when the last of them does; with
+        // units handed out in image order the last ones started can be the long ones.  Two remedies,
+        // neither of which changes a bit (a pixel's sums continue in sample order, as
+        // rtx_accumulate_samples does): a first launch of kProbeSamples samples that records what each
+        // unit costs, so that the rest can be dispatched longest first; and the sample range cut into
+        // chunks that waves draw from a queue, so that the last items to run are short.
         uint32_t probe = 0;
         uint32_t *tiles = nullptr;
         if (!stats && sample_count >= kOrderedMinSamples && n_tiles >= kOrderedMinTiles) {
@@ -969,22 +981,33 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
             if (no_alloc) {
                 tiles = c->static_tiles;
             } else {
-                if (c->d_tiles_words < 2u * (size_t)n_tiles) {
+                // cost | order | work queue (a ticket counter and one word per unit)
+                const size_t words = 3u * (size_t)n_tiles + 64u;
+                if (c->d_tiles_words < words) {
                     if (c->d_tiles) (void)hipFree(c->d_tiles);
                     c->d_tiles = nullptr;
                     c->d_tiles_words = 0;
-                    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_tiles), 2u * (size_t)n_tiles * sizeof(uint32_t)));
-                    c->d_tiles_words = 2u * (size_t)n_tiles;
+                    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_tiles), words * sizeof(uint32_t)));
+                    c->d_tiles_words = words;
                 }
                 tiles = c->d_tiles;
             }
         }
+        // The rest of the launch plan depends on the kernel (measured, ms per frame, queue alone / cost
+        // order + queue / cost order alone): the two-pixel scan kernel takes the work queue alone (reference
+        // scene at 1920x1080x256: 61.1 / 61.8 / 65.0; at 3840x2160x1024: 938 / 939 / 946); the one-pixel kernels take the
+        // cost order and, with chunks of 32 samples or more, the queue as well (glass scene, 256 samples: 210 / 202 /
+        // 208; 10 000 objects, 64 samples, two chunks of 28: 148 / 145 / 140 -- short chunks cost more in
+        // lanes that wait at each chunk's end than the shorter end of the launch returns).
+        const bool two_pixel = probe != 0u && rtx::megakernel_two_pixels(P, c->src);
+        if (two_pixel) probe = 0u;
+        const uint32_t chunk_min = two_pixel ? kChunkMin : kChunkMinOnePixel;
         if (probe) {
             // the launch deals out work units (8 x 8 tiles or pairs of them): at most n_tiles
             const uint32_t n_units = rtx::megakernel_units(P, c->src);
             uint32_t *cost = tiles, *order = tiles + n_tiles;
             // the tables keep the last call's contents: costs are maxima and must start from zero
-            HIP_TRY(hipMemsetAsync(cost, 0, n_tiles * sizeof(uint32_t), stream));
+            HIP_TRY(rtx::launch_zero_words(cost, n_tiles, stream));
             rtx::RenderParams A = P;
             A.sample_count = probe;
             A.tile_cost = cost;
@@ -994,6 +1017,17 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
             P.sample_count = sample_count - probe;
             P.accumulate = 1u;
             P.tile_order = order;
+        }
+        if (tiles) {
+            // the samples in chunks -- halves of what is left, down to chunk_min samples -- drawn from a
+            // queue, so that the launch ends with short work items instead of whole units (rtx_device.h)
+            uint32_t chunks = 1u;
+            while (chunks < kChunkMax && (P.sample_count >> chunks) >= chunk_min) ++chunks;
+            if (chunks > 1u) {
+                P.queue = tiles + 2u * (size_t)n_tiles;
+                P.n_chunks = chunks;
+                HIP_TRY(rtx::launch_zero_words(P.queue, 1u + (uint64_t)rtx::megakernel_units(P, c->src), stream));
+            }
         }
         HIP_TRY(rtx::launch_megakernel(P, c->src, stats, c->pool_limit, stream));
     }

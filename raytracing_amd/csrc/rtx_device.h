@@ -84,6 +84,17 @@ struct RenderParams {
     // the identity; and where a recording launch leaves each tile's cost (nullptr: not recorded).
     const uint32_t *tile_order;
     uint32_t *tile_cost;
+    // Work queue of the two-pixel scan kernel (nullptr: every wave runs the unit of its launch slot for
+    // all samples).  The sample range is cut into n_chunks chunks -- halves of what is left, the last
+    // two alike -- and the launch has a wave per (chunk, unit) item, each drawing its item from
+    // queue[0], a ticket counter (whatever order the hardware starts the waves in, a lower ticket is held
+    // by a wave that has started): all units' first chunks in tile_order, then all second ones, and so
+    // on.  queue[1 + unit] = chunks
+    // of that unit that are complete: a unit's chunk k + 1 continues the sums chunk k left, so it waits
+    // for that count to reach k + 1.  The end of a launch is then made of short items, and the order
+    // in which a pixel's samples are added does not change.  All zero before the launch.
+    uint32_t *queue;
+    uint32_t n_chunks;
     uint32_t ellipsoids_pow2;      // 1: every ellipsoid's radii are powers of two (kGeomPow2)
     uint32_t paths_end_at_lights;  // 1: a small all-diffuse scene whose lights are black (set at upload; picks the two-pixel scan kernel)
     uint32_t pool_entries;  // megakernel: float4 entries of a wave's hand-over pool in LDS (set by the launcher)
@@ -105,10 +116,13 @@ constexpr uint32_t kFewLights = 2;
 hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, uint32_t pool_limit, hipStream_t stream);
 // work units of a megakernel launch: what tile_order permutes and tile_cost is indexed by
 uint32_t megakernel_units(const RenderParams &p, int src);
+// whether the megakernel chosen for (p, src) is the two-pixel scan kernel
+bool megakernel_two_pixels(const RenderParams &p, int src);
 // order[0..n_tiles) = the tiles by decreasing cost[] (buckets of one unit, costs above
 // kTileCostMax share the first bucket)
 constexpr uint32_t kTileCostMax = 2047u;
 constexpr uint32_t kPoolEntriesMax = 1023u;
+hipError_t launch_zero_words(uint32_t *p, uint64_t n, hipStream_t stream);
 hipError_t launch_tile_order(const uint32_t *cost, uint32_t *order, uint32_t n_tiles, hipStream_t stream);
 hipError_t launch_primary(const RenderParams &p, const PrimaryParams &out, int src, hipStream_t stream);
 hipError_t launch_divide(float *d, uint64_t n, float divisor, hipStream_t stream);

@@ -169,14 +169,57 @@ RTX_DEV uint32_t wave_max(uint32_t v)
 // RECORD: the launch also leaves in P.tile_cost[tile] (zero before the launch) the largest number
 // of rays one lane of the tile's wave traced -- what the wave's running time follows.
 constexpr uint32_t kNoEntry = 0x3ffu;   // end of a list; pool entries are numbered below it
-template <int SRC, bool STATS, bool MANY_LIGHTS, bool RECORD = false>
+
+// A wave's work item when the launch has a work queue (RenderParams::queue): one wave per (chunk of the
+// sample range, unit), every wave drawing a ticket.  Tickets go chunk by chunk -- all units' first chunks
+// before all second ones -- and a unit's chunks continue its pixels' sums one after the other, so a chunk
+// waits for the one before it.  Returns false for a wave beyond the last item.
+RTX_DEV bool queue_take_item(const RenderParams &P, uint32_t slot, uint32_t n_units, uint32_t &unit, uint32_t &chunk,
+                             uint32_t &sample_first, uint32_t &sample_count, bool &accumulate)
+{
+    if (slot >= n_units * P.n_chunks) return false;
+    uint32_t ticket = 0;
+    if ((threadIdx.x & 63u) == 0u) ticket = atomicAdd(P.queue, 1u);
+    ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
+    chunk = ticket / n_units;
+    unit = ticket - chunk * n_units;
+    if (P.tile_order) unit = P.tile_order[unit];
+    // chunk k of n samples: [n - (n >> k), n - (n >> (k + 1))), the last one up to n
+    const uint32_t lo = P.sample_count - (P.sample_count >> chunk);
+    const uint32_t hi = chunk + 1u == P.n_chunks ? P.sample_count : P.sample_count - (P.sample_count >> (chunk + 1u));
+    sample_first = P.sample_first + lo;
+    sample_count = hi - lo;
+    if (chunk != 0u) {
+        // The unit's previous chunk has a lower ticket, so a wave that is running (or through) holds it:
+        // wait for its sums.  (Bounded, so that a mistake here ends in wrong pixels, not in a hung GPU.)
+        accumulate = true;
+        const uint32_t *done = P.queue + 1u + unit;
+        for (uint32_t spin = 0; spin < (1u << 24) && __hip_atomic_load(done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunk; ++spin)
+            __builtin_amdgcn_s_sleep(16);
+        __threadfence();   // acquire: nothing below reads the sums from a stale cache line
+    }
+    return true;
+}
+// the item's sums are written: whichever wave takes the unit's next chunk may read them
+RTX_DEV void queue_item_done(const RenderParams &P, uint32_t unit, uint32_t chunk)
+{
+    __threadfence();
+    if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(P.queue + 1u + unit, chunk + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int SRC, bool STATS, bool MANY_LIGHTS, bool RECORD = false, bool QUEUE = false>
 __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const RenderParams P)
 {
     Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
     const uint32_t tiles_x = (P.width + 7u) >> 3;
     uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (tile >= tiles_x * ((P.height + 7u) >> 3)) return;   // the whole wave
-    if (P.tile_order) tile = P.tile_order[tile];
+    uint32_t sample_first = P.sample_first, sample_count = P.sample_count, chunk = 0;
+    bool accumulate = P.accumulate != 0u;
+    if constexpr (QUEUE) {
+        if (!queue_take_item(P, tile, tiles_x * ((P.height + 7u) >> 3), tile, chunk, sample_first, sample_count, accumulate)) return;
+    } else {
+        if (tile >= tiles_x * ((P.height + 7u) >> 3)) return;   // the whole wave
+        if (P.tile_order) tile = P.tile_order[tile];
+    }
     const uint32_t tile_x = (tile % tiles_x) * 8u, tile_y = (tile / tiles_x) * 8u;
     const bool in_image = tile_x + (threadIdx.x & 7u) < P.width && tile_y + ((threadIdx.x & 63u) >> 3) < P.height;
     // the wave's pool, behind the object table (scan) or the traversal stacks (BVH)
@@ -188,12 +231,12 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
     cnt.clear();
     const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
     V3 sum = v3(0.0f, 0.0f, 0.0f);
-    if (in_image && P.accumulate) {
+    if (in_image && accumulate) {
         const float *out = P.out_sum + 3ull * ((tile_y + ((threadIdx.x & 63u) >> 3)) * P.width + tile_x + (threadIdx.x & 7u));
         sum = v3(out[0], out[1], out[2]);
     }
-    const uint32_t last = P.sample_first + P.sample_count;
-    uint32_t next = in_image ? P.sample_first : last;   // own samples [next, end) are not started yet
+    const uint32_t last = sample_first + sample_count;
+    uint32_t next = in_image ? sample_first : last;   // own samples [next, end) are not started yet
     uint32_t end = last;                                // own samples [end, last) were handed over
     uint32_t head = kNoEntry;                           // entry of own sample `end`, the list's first
     Path p;
@@ -414,6 +457,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
         out[2] = total.z;
     }
     if constexpr (RECORD) atomicMax(&P.tile_cost[tile], rays);
+    if constexpr (QUEUE) queue_item_done(P, tile, chunk);
     if constexpr (STATS) {
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i)
@@ -447,6 +491,11 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
 #define RTX_MK2_SCATTER_MIN 50u
 #endif
 constexpr uint32_t kParkVec = 6u;   // float4 per parked context
+// threads per workgroup of k_megakernel_scan2 (a multiple of 64)
+#ifndef RTX_MK2_BLOCK
+#define RTX_MK2_BLOCK 256
+#endif
+constexpr uint32_t kScan2Block = RTX_MK2_BLOCK;
 enum : uint32_t { kPhaseEmpty = 0u,    // no sample in flight, none of its own left to start
                   kPhaseIdle = 1u,     // no sample in flight, own samples left
                   kPhaseScan = 2u,     // a ray whose closest hit is wanted
@@ -461,16 +510,16 @@ struct PixelContext {
 };
 RTX_DEV void park_store(float4 *park, const PixelContext &c)
 {
-    park[0 * 256] = make_float4(c.p.o.x, c.p.o.y, c.p.o.z, c.p.T.x);
-    park[1 * 256] = make_float4(c.p.d.x, c.p.d.y, c.p.d.z, c.p.T.y);
-    park[2 * 256] = make_float4(c.p.L.x, c.p.L.y, c.p.L.z, c.p.T.z);
-    park[3 * 256] = make_float4(c.sum.x, c.sum.y, c.sum.z, c.hit_t);
-    park[4 * 256] = make_float4(__uint_as_float(c.s), __uint_as_float(c.job), __uint_as_float(c.next), __uint_as_float(c.end));
-    park[5 * 256] = make_float4(__uint_as_float(c.head), __uint_as_float(c.p.depth), __int_as_float(c.hit_idx), __uint_as_float(c.phase));
+    park[0 * kScan2Block] = make_float4(c.p.o.x, c.p.o.y, c.p.o.z, c.p.T.x);
+    park[1 * kScan2Block] = make_float4(c.p.d.x, c.p.d.y, c.p.d.z, c.p.T.y);
+    park[2 * kScan2Block] = make_float4(c.p.L.x, c.p.L.y, c.p.L.z, c.p.T.z);
+    park[3 * kScan2Block] = make_float4(c.sum.x, c.sum.y, c.sum.z, c.hit_t);
+    park[4 * kScan2Block] = make_float4(__uint_as_float(c.s), __uint_as_float(c.job), __uint_as_float(c.next), __uint_as_float(c.end));
+    park[5 * kScan2Block] = make_float4(__uint_as_float(c.head), __uint_as_float(c.p.depth), __int_as_float(c.hit_idx), __uint_as_float(c.phase));
 }
 RTX_DEV PixelContext park_load(const float4 *park)
 {
-    const float4 a = park[0 * 256], b = park[1 * 256], c = park[2 * 256], d = park[3 * 256], e = park[4 * 256], f = park[5 * 256];
+    const float4 a = park[0 * kScan2Block], b = park[1 * kScan2Block], c = park[2 * kScan2Block], d = park[3 * kScan2Block], e = park[4 * kScan2Block], f = park[5 * kScan2Block];
     PixelContext x;
     x.p.o = v3(a.x, a.y, a.z);
     x.p.d = v3(b.x, b.y, b.z);
@@ -492,26 +541,42 @@ RTX_DEV PixelContext park_load(const float4 *park)
 __host__ __device__ inline uint32_t scan_units_x(uint32_t width) { return (width + 15u) >> 4; }
 __host__ __device__ inline uint32_t scan_units(uint32_t width, uint32_t height) { return scan_units_x(width) * ((height + 7u) >> 3); }
 
-template <int SRC, bool STATS, bool MANY_LIGHTS, bool RECORD = false>
-__global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel_scan2(const RenderParams P)
+template <int SRC, bool STATS, bool MANY_LIGHTS, bool RECORD = false, bool QUEUE = false>
+__global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_scan2(const RenderParams P)
 {
     static_assert(SRC != kSrcBvh, "the two-pixel kernel is the linear scan's");
     Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
-    uint32_t unit = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (unit >= scan_units(P.width, P.height)) return;   // the whole wave
-    if (P.tile_order) unit = P.tile_order[unit];
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t unit_x = (unit % scan_units_x(P.width)) * 16u + (lane & 7u), unit_y = (unit / scan_units_x(P.width)) * 8u + (lane >> 3);
     // LDS: [object table][parked contexts of the workgroup][the waves' pools]
     float4 *park = rtx_smem + fixed_lds_bytes<SRC>(P) / 16u + threadIdx.x;
-    float4 *pool = rtx_smem + fixed_lds_bytes<SRC>(P) / 16u + kParkVec * 256u + (threadIdx.x >> 6) * P.pool_entries;
-    uint32_t pool_used = 0;   // wave-uniform
-
-    uint32_t rays = 0;
+    float4 *pool = rtx_smem + fixed_lds_bytes<SRC>(P) / 16u + kParkVec * kScan2Block + (threadIdx.x >> 6) * P.pool_entries;
     Counters<STATS> cnt;
     cnt.clear();
     const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
-    const uint32_t last = P.sample_first + P.sample_count;
+    uint32_t dbg[M_COUNT] = {};
+    (void)dbg;
+    const uint32_t n_units = scan_units(P.width, P.height);
+    // The wave's work item.  Without a queue: the unit of its launch slot, all samples.  With a queue
+    // (P.queue, see RenderParams) the launch has one wave per (chunk of the sample range, unit) and every
+    // wave draws a ticket: tickets go chunk by chunk -- all units' first chunks before all second ones --
+    // and a unit's chunks continue its pixels' sums one after the other.
+    const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    uint32_t unit, sample_first, sample_count, chunk = 0;
+    bool accumulate = P.accumulate != 0u;
+    if constexpr (QUEUE) {
+        if (!queue_take_item(P, slot, n_units, unit, chunk, sample_first, sample_count, accumulate)) return;   // the whole wave
+    } else {
+        unit = slot;
+        if (unit >= n_units) return;   // the whole wave
+        if (P.tile_order) unit = P.tile_order[unit];
+        sample_first = P.sample_first;
+        sample_count = P.sample_count;
+    }
+    const uint32_t unit_x = (unit % scan_units_x(P.width)) * 16u + (lane & 7u), unit_y = (unit / scan_units_x(P.width)) * 8u + (lane >> 3);
+    uint32_t pool_used = 0;   // wave-uniform
+
+    uint32_t rays = 0;
+    const uint32_t last = sample_first + sample_count;
     auto fresh_context = [&](uint32_t half) {
         PixelContext c;
         c.p.o = c.p.d = c.p.T = c.p.L = v3(0.0f, 0.0f, 0.0f);
@@ -519,13 +584,13 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel_scan2(co
         c.sum = v3(0.0f, 0.0f, 0.0f);
         const uint32_t px = unit_x + 8u * half;
         const bool in_image = px < P.width && unit_y < P.height;
-        if (in_image && P.accumulate) {
+        if (in_image && accumulate) {
             const float *out = P.out_sum + 3ull * (unit_y * P.width + px);
             c.sum = v3(out[0], out[1], out[2]);
         }
         c.s = 0;
         c.job = lane | (half << 6);
-        c.next = in_image ? P.sample_first : last;   // own samples [next, end) are not started yet
+        c.next = in_image ? sample_first : last;     // own samples [next, end) are not started yet
         c.end = last;                                // own samples [end, last) were handed over
         c.head = kNoEntry;                           // entry of own sample `end`, the list's first
         c.hit_idx = -1;
@@ -558,8 +623,6 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel_scan2(co
         set_phase(c.next < c.end ? kPhaseIdle : kPhaseEmpty);
     };
     auto scannable = [](uint32_t ph) { return ph == kPhaseIdle || ph == kPhaseScan; };
-    uint32_t dbg[M_COUNT] = {};
-    (void)dbg;
 
     for (;;) {
         MK_DBG(M_ROUNDS, 1u);
@@ -701,6 +764,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel_scan2(co
         if (k == 0) c = park_load(park);
     }
     if constexpr (RECORD) atomicMax(&P.tile_cost[unit], rays);
+    if constexpr (QUEUE) queue_item_done(P, unit, chunk);
     if constexpr (STATS) {
 #pragma unroll
         for (int i = 0; i < C_COUNT; ++i)
@@ -764,6 +828,13 @@ __global__ void __launch_bounds__(256) k_tonemap(const float *sum, uint64_t n, f
     }
 }
 
+// Clears the tile tables before a launch that uses them.  (A kernel rather than hipMemsetAsync: inside a
+// captured graph the memset nodes of these calls were seen to clear the tables on the first replay only.)
+__global__ void __launch_bounds__(256) k_zero_words(uint32_t *p, uint64_t n)
+{
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+
 // Counting sort of the tiles by decreasing cost, one workgroup.  Tiles of equal cost land in
 // the order their atomics happen to be served: the order table only decides which wave starts
 // when, never what it computes.
@@ -804,6 +875,9 @@ static void launch_megakernel_src(const RenderParams &p, bool stats, dim3 grid, 
     } else if (p.tile_cost) {
         if (many) hipLaunchKernelGGL((k_megakernel<SRC, false, true, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((k_megakernel<SRC, false, false, true>), grid, block, lds, stream, p);
+    } else if (p.queue) {
+        if (many) hipLaunchKernelGGL((k_megakernel<SRC, false, true, false, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((k_megakernel<SRC, false, false, false, true>), grid, block, lds, stream, p);
     } else {
         if (many) hipLaunchKernelGGL((k_megakernel<SRC, false, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((k_megakernel<SRC, false, false>), grid, block, lds, stream, p);
@@ -812,7 +886,7 @@ static void launch_megakernel_src(const RenderParams &p, bool stats, dim3 grid, 
 template <int SRC>
 static void launch_megakernel_scan2(const RenderParams &p, bool stats, dim3 grid, size_t lds, hipStream_t stream)
 {
-    const dim3 block(256);
+    const dim3 block(kScan2Block);
     const bool many = p.n_lights > kFewLights;
     if (stats) {
         if (many) hipLaunchKernelGGL((k_megakernel_scan2<SRC, true, true>), grid, block, lds, stream, p);
@@ -820,6 +894,9 @@ static void launch_megakernel_scan2(const RenderParams &p, bool stats, dim3 grid
     } else if (p.tile_cost) {
         if (many) hipLaunchKernelGGL((k_megakernel_scan2<SRC, false, true, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((k_megakernel_scan2<SRC, false, false, true>), grid, block, lds, stream, p);
+    } else if (p.queue) {
+        if (many) hipLaunchKernelGGL((k_megakernel_scan2<SRC, false, true, false, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((k_megakernel_scan2<SRC, false, false, false, true>), grid, block, lds, stream, p);
     } else {
         if (many) hipLaunchKernelGGL((k_megakernel_scan2<SRC, false, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((k_megakernel_scan2<SRC, false, false>), grid, block, lds, stream, p);
@@ -832,7 +909,7 @@ static void launch_megakernel_scan2(const RenderParams &p, bool stats, dim3 grid
 static bool two_pixels_per_lane(const RenderParams &p, int src)
 {
     return RTX_MK_TWO && src != kSrcBvh && p.paths_end_at_lights != 0u &&
-           fixed_lds_bytes(p, src) + kParkVec * 256u * sizeof(float4) <= 40u * 1024u;
+           fixed_lds_bytes(p, src) + kParkVec * kScan2Block * sizeof(float4) <= 40u * 1024u * kScan2Block / 256u;
 }
 // work units a megakernel launch deals out to its waves (and the tile cost / order tables index):
 // 8x8 tiles, or pairs of them (16x8 pixels) for the two-pixel kernel
@@ -842,25 +919,37 @@ uint32_t megakernel_units(const RenderParams &p, int src)
     return ((p.width + 7u) / 8u) * ((p.height + 7u) / 8u);
 }
 
+bool megakernel_two_pixels(const RenderParams &p, int src) { return two_pixels_per_lane(p, src); }
+
 hipError_t launch_megakernel(const RenderParams &p0, int src, bool stats, uint32_t pool_limit, hipStream_t stream)
 {
     RenderParams p = p0;
     const bool two = two_pixels_per_lane(p, src);
-    const dim3 grid((megakernel_units(p, src) + 3u) / 4u);
-    // four workgroups share a CU's 160 KB of LDS: what the table (scan) or the traversal
-    // stacks (BVH), and the parked pixel contexts of the two-pixel kernel, leave of 40 KB goes to
-    // the four waves' hand-over pools
-    const size_t fixed = fixed_lds_bytes(p, src) + (two ? kParkVec * 256u * sizeof(float4) : 0u);
-    const size_t budget = 40u * 1024u;
-    p.pool_entries = fixed < budget ? (uint32_t)std::min<size_t>(kPoolEntriesMax, (budget - fixed) / (4u * sizeof(float4))) : 0u;
+    if (stats) p.queue = nullptr;
+    const uint32_t waves = two ? kScan2Block / 64u : 4u;   // per workgroup
+    const uint32_t slots = megakernel_units(p, src) * (p.queue ? p.n_chunks : 1u);   // a wave per work item
+    const dim3 grid((slots + waves - 1u) / waves);
+    // sixteen waves share a CU's 160 KB of LDS: what the table (scan) or the traversal
+    // stacks (BVH), and the parked pixel contexts of the two-pixel kernel, leave of a workgroup's
+    // 10 KB per wave goes to its waves' hand-over pools
+    const size_t fixed = fixed_lds_bytes(p, src) + (two ? kParkVec * kScan2Block * sizeof(float4) : 0u);
+    const size_t budget = 10u * 1024u * waves;
+    p.pool_entries = fixed < budget ? (uint32_t)std::min<size_t>(kPoolEntriesMax, (budget - fixed) / (waves * sizeof(float4))) : 0u;
     p.pool_entries = std::min(p.pool_entries, pool_limit);
-    const size_t lds = fixed + (size_t)p.pool_entries * 4u * sizeof(float4);
+    const size_t lds = fixed + (size_t)p.pool_entries * waves * sizeof(float4);
     if (two) {
         if (src == kSrcLds) launch_megakernel_scan2<kSrcLds>(p, stats, grid, lds, stream);
         else launch_megakernel_scan2<kSrcScalar>(p, stats, grid, lds, stream);
     } else if (src == kSrcLds) launch_megakernel_src<kSrcLds>(p, stats, grid, lds, stream);
     else if (src == kSrcScalar) launch_megakernel_src<kSrcScalar>(p, stats, grid, lds, stream);
     else launch_megakernel_src<kSrcBvh>(p, stats, grid, lds, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_zero_words(uint32_t *p, uint64_t n, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_zero_words, dim3((uint32_t)std::min<uint64_t>((n + 255u) / 256u, 1024u)), dim3(256), 0, stream, p, n);
     return hipGetLastError();
 }
 
