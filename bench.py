@@ -309,6 +309,7 @@ def main():
     ap.add_argument("--reduce", default="p2p", choices=["p2p", "rccl"], help="in-library driver: how the GPUs' sums are added")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stats", action="store_true")
+    ap.add_argument("--no-host", action="store_true", help="skip the timing of rtx_render into host memory (profiling runs: only the timed steps launch kernels)")
     ap.add_argument("--no-extra", action="store_true", help="N = 1: only the headline workload, not the other configurations")
     args = ap.parse_args()
 
@@ -357,7 +358,7 @@ def main():
     single = world == 1
     head = measure(name, args.mode, args.accel, args.steps, args.warmup, want_stats=not args.no_stats, spp=args.spp,
                    size=args.size, depth=args.depth, stats_spp=64 if name == "c4" and not args.spp else None,
-                   host_steps=2 if run["driver"] == "library" else 0, **common)
+                   host_steps=2 if run["driver"] == "library" and not args.no_host else 0, **common)
 
     # N = 1, default workload: the other configurations in the same run, all GPU work in one block
     # before the CPU baselines

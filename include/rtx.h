@@ -259,6 +259,14 @@ int rtx_last_kernel_ms(rtx_ctx *ctx, float *ms);
 /* Number of lights derived from the current scene, and their object indices. */
 int rtx_get_lights(rtx_ctx *ctx, int32_t *indices, int32_t capacity);
 
+/* Page-locked host memory for the images rtx_render, rtx_render_bytes and rtx_progress_read write.
+ * No counterpart in the reference (its image is a Vec, src/image.rs:7-10).  Any host memory is
+ * accepted by those calls; into pageable memory the runtime stages the device-to-host copies one
+ * after the other, into memory from here the GPUs of a multi-GPU context deliver their slices of the
+ * image side by side.  *out = NULL for 0 bytes. */
+int rtx_alloc_pinned(void **out, uint64_t bytes);
+void rtx_free_pinned(void *p);
+
 /* Number of GPUs the context drives (1 unless rtx_opts.n_devices asked for more). */
 int rtx_device_count(rtx_ctx *ctx);
 

@@ -133,6 +133,8 @@ extern "C" {
     pub fn rtx_last_kernel_ms(ctx: *mut rtx_ctx, ms: *mut f32) -> c_int;
     pub fn rtx_get_lights(ctx: *mut rtx_ctx, indices: *mut i32, capacity: i32) -> c_int;
     pub fn rtx_device_count(ctx: *mut rtx_ctx) -> c_int;
+    pub fn rtx_alloc_pinned(out: *mut *mut c_void, bytes: u64) -> c_int;
+    pub fn rtx_free_pinned(p: *mut c_void);
     pub fn rtx_last_error() -> *const c_char;
     pub fn rtx_abi_version() -> u32;
 }

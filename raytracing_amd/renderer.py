@@ -43,6 +43,8 @@ SYMBOLS = {
     "rtx_last_kernel_ms": (C.c_int, [C.c_void_p, _FP]),
     "rtx_get_lights": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int32]),
     "rtx_device_count": (C.c_int, [C.c_void_p]),
+    "rtx_alloc_pinned": (C.c_int, [C.POINTER(C.c_void_p), C.c_uint64]),
+    "rtx_free_pinned": (None, [C.c_void_p]),
 }
 
 _lib = None
@@ -85,6 +87,30 @@ def _check(rc: int):
     if rc < 0:
         raise RtxError(rc, load_library().rtx_last_error().decode("utf-8", "replace"))
     return rc
+
+
+class PinnedImage:
+    """A float32 (height, width, 3) array in page-locked host memory (rtx_alloc_pinned): what
+    Renderer.render(..., out=) writes into without the runtime staging the copy."""
+
+    def __init__(self, height: int, width: int):
+        self._lib = load_library()
+        self._ptr = C.c_void_p()
+        n = height * width * 3
+        _check(self._lib.rtx_alloc_pinned(C.byref(self._ptr), n * 4))
+        self.array = np.ctypeslib.as_array(C.cast(self._ptr, _FP), shape=(n,)).reshape(height, width, 3)
+
+    def close(self):
+        if getattr(self, "_ptr", None):
+            self.array = None
+            self._lib.rtx_free_pinned(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Renderer:
@@ -141,10 +167,14 @@ class Renderer:
         return list(buf[:n])
 
     # -- drop-in for render(&mut scene) -----------------------------------
-    def render(self, scene: Scene) -> np.ndarray:
-        """Mean linear radiance, shape (height, width, 3), row 0 = top."""
+    def render(self, scene: Scene, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Mean linear radiance, shape (height, width, 3), row 0 = top.  out: a C-contiguous float32
+        array of that shape to write into (e.g. PinnedImage.array)."""
         s, keep = scene.to_ctypes()
-        out = np.empty((scene.height, scene.width, 3), dtype=np.float32)
+        if out is None:
+            out = np.empty((scene.height, scene.width, 3), dtype=np.float32)
+        elif out.dtype != np.float32 or out.shape != (scene.height, scene.width, 3) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous float32 array of shape (height, width, 3)")
         _check(self._lib.rtx_render(self._ctx, C.byref(s), out.ctypes.data_as(_FP)))
         self._scene = scene
         return out

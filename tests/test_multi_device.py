@@ -160,6 +160,22 @@ def test_distinct_gpus_both_reduces(oracle):
         assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
 
 
+def test_render_into_pinned_memory_has_the_same_bits():
+    from raytracing_amd.renderer import PinnedImage
+    sc = reference_scene(width=97, height=43, n_samples=5)
+    img = PinnedImage(sc.height, sc.width)
+    try:
+        for opts in (dict(), dict(devices=[0, 0, 0])):
+            with Renderer(seed=6, **opts) as r:
+                want = r.render(sc)
+                img.array.fill(np.nan)
+                got = r.render(sc, out=img.array)
+                assert got is img.array
+                assert np.array_equal(want.view(np.uint32), img.array.view(np.uint32))
+    finally:
+        img.close()
+
+
 def test_full_hd_frame_split_in_two(oracle):
     """The slice reduce at a real size: 1920 x 1080, two workers, against the unsplit render."""
     sc = reference_scene(width=1920, height=1080, n_samples=4)

@@ -7,6 +7,6 @@ out=$root/build_variants/$name
 mkdir -p $out
 cd $root/raytracing_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -Wno-unused-function $flags -x hip -c -o $out/rtx_api.o rtx_api.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/librtx.so $out/rtx_api.o build/rtx_kernels.o build/rtx_wavefront.o build/rtx_bvh.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/librtx.so $out/rtx_api.o build/rtx_kernels.o build/rtx_wavefront.o build/rtx_bvh.o -ldl -pthread
 rm -f $out/*.o
 echo built $out/librtx.so

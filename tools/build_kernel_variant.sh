@@ -8,6 +8,6 @@ out=$root/build_variants/$name
 mkdir -p $out
 cd $root/raytracing_amd/csrc
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -Wno-unused-function $flags -x hip -c -o $out/rtx_kernels.o rtx_kernels.hip
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/librtx.so $out/rtx_kernels.o build/rtx_api.o build/rtx_wavefront.o build/rtx_bvh.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/librtx.so $out/rtx_kernels.o build/rtx_api.o build/rtx_wavefront.o build/rtx_bvh.o -ldl -pthread
 rm -f $out/*.o
 echo built $out/librtx.so

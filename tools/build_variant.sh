@@ -11,6 +11,6 @@ for f in rtx_api.hip rtx_kernels.hip rtx_wavefront.hip rtx_bvh.cpp; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize --offload-arch=gfx950 -Wno-unused-function $flags -x hip -c -o $out/${f%.*}.o $f &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/librtx.so $out/*.o -ldl
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $out/librtx.so $out/*.o -ldl -pthread
 rm -f $out/*.o
 echo built $out/librtx.so

@@ -28,16 +28,28 @@ lib.rtx_last_kernel_ms.argtypes = [C.c_void_p, FP]
 lib.rtx_destroy.argtypes = [C.c_void_p]
 lib.rtx_last_error.restype = C.c_char_p
 
+pinned_ok = hasattr(lib, "rtx_alloc_pinned")
+if pinned_ok:
+    lib.rtx_alloc_pinned.argtypes = [C.POINTER(C.c_void_p), C.c_uint64]
+    lib.rtx_free_pinned.argtypes = [C.c_void_p]
+
 sc = reference_scene(w, h, spp, 6)
 s, keep = sc.to_ctypes()
-for n in (1, workers):
+for n, pinned in ((1, False), (workers, False), (1, True), (workers, True)):
+    if pinned and not pinned_ok:
+        continue
     o = _abi.rtx_opts()
     o.seed = 1
     devs = (C.c_int32 * n)(*([0] * n))
     o.n_devices, o.devices = n, devs
     ctx = C.c_void_p()
     assert lib.rtx_create(C.byref(ctx), C.byref(o)) == 0, lib.rtx_last_error()
-    out = np.empty((h, w, 3), dtype=np.float32)
+    if pinned:
+        ptr = C.c_void_p()
+        assert lib.rtx_alloc_pinned(C.byref(ptr), h * w * 12) == 0, lib.rtx_last_error()
+        out = np.ctypeslib.as_array(C.cast(ptr, FP), shape=(h * w * 3,)).reshape(h, w, 3)
+    else:
+        out = np.empty((h, w, 3), dtype=np.float32)
     rows = []
     for k in range(6):
         t0 = time.perf_counter()
@@ -50,5 +62,5 @@ for n in (1, workers):
     rows = rows[2:]
     e2e = sum(r[0] for r in rows) / len(rows)
     ker = sum(r[1] for r in rows) / len(rows)
-    print(f"{os.path.basename(os.path.dirname(path)) or 'in-tree'} workers={n} {w}x{h}x{spp}: rtx_render {e2e:.2f} ms, "
+    print(f"{os.path.basename(os.path.dirname(path)) or 'in-tree'} workers={n} {'pinned' if pinned else 'pageable'} {w}x{h}x{spp}: rtx_render {e2e:.2f} ms, "
           f"slowest worker's kernels {ker:.2f} ms, beyond the kernels {e2e - ker:.2f} ms  checksum {float(out.astype(np.float64).sum()):.6e}")

@@ -8,9 +8,9 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$R/gpurun_out/prof_${W}_${M}
 mkdir -p "$OUT"
-B="python3 $R/bench.py --workload $W --mode $M --steps 1 --warmup 0 --no-cpu-baseline --no-stats $*"
+B="python3 $R/bench.py --workload $W --mode $M --steps 1 --warmup 0 --no-cpu-baseline --no-stats --no-host $*"
 cd /tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --workload "$W" --mode "$M" --steps 3 --warmup 1 --no-cpu-baseline "$@" > "$OUT/trace.log" 2>&1
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$R/bench.py" --workload "$W" --mode "$M" --steps 3 --warmup 1 --no-cpu-baseline --no-host "$@" > "$OUT/trace.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_WAIT_INST_ANY --output-format csv -d "$OUT/a" -- $B > "$OUT/a.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VALU_CVT --output-format csv -d "$OUT/b" -- $B > "$OUT/b.log" 2>&1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d "$OUT/c" -- $B > "$OUT/c.log" 2>&1
