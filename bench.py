@@ -29,9 +29,11 @@ Workloads:
   c3  synthetic 10k-object scene, 1080p, 64 spp, BVH
   c5  dielectric / metallic scene, depth 16, 1080p, 256 spp
   c1  reference scene as shipped: 512x512, 10 spp
+  c2lit  c2 with a coloured light: the scene class the two-pixel kernel is not chosen for
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import dataclasses
 import json
 import os
 import re
@@ -52,6 +54,14 @@ def build_workload(name, spp_override=None, size_override=None):
         sc, desc = synthetic_scene(10000, 12345, 1920, 1080, 64, 6), "synthetic 10k objects (8 lights), 1920x1080, 64 spp, depth 6, BVH"
     elif name == "c5":
         sc, desc = dielectric_scene(1920, 1080, 256, 16), "dielectric/metallic scene (33 objects), 1920x1080, 256 spp, depth 16"
+    elif name == "c2lit":
+        # not a configuration of the baseline: c2 with a COLOR line on its light (albedo 0.78).  Paths no
+        # longer end at the light, so the library picks its general one-pixel kernel instead of the
+        # two-pixel one that the reference's own scene (black light) gets
+        sc = reference_scene(1920, 1080, 256, 6)
+        prims = list(sc.prims)
+        prims[5] = dataclasses.replace(prims[5], color=(0.78, 0.78, 0.78))
+        sc, desc = sc.replace(prims=prims), "reference scene with a COLOR 0.78 line on its light, 1920x1080, 256 spp, depth 6"
     elif name == "c1":
         sc, desc = reference_scene(512, 512, 10, 6), "reference scene at its native 512x512, 10 spp, depth 6"
     elif name[0] == "s" and name[1:].isdigit():
@@ -366,7 +376,7 @@ def main():
     if single and args.workload is None and not args.no_extra and run["driver"] == "library" and args.reduce == "p2p":
         for key, wl, mode, steps in (("c2", "c2", "megakernel", 5), ("c3", "c3", "megakernel", 3), ("c3_wavefront", "c3", "wavefront", 3),
                                      ("c5", "c5", "megakernel", 3), ("c5_wavefront", "c5", "wavefront", 3),
-                                     ("c2_wavefront", "c2", "wavefront", 3)):
+                                     ("c2_wavefront", "c2", "wavefront", 3), ("c2_coloured_light", "c2lit", "megakernel", 3)):
             m = measure(wl, mode, "auto", steps, 1, want_stats=not args.no_stats, host_steps=2 if key == "c2" else 0, **common)
             m.pop("elapsed")
             extra[key] = m

@@ -173,9 +173,9 @@ int rtx_render_samples(rtx_ctx *ctx, uint32_t sample_first, uint32_t sample_coun
 /* rtx_render_samples for callers that cannot allocate device memory: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
  * reference.  Same arguments, same output bits as rtx_render_samples, but no device or pinned
- * memory is allocated or freed on any path: the tile cost / dispatch order tables of the
- * megakernel live in a static device array of RTX_STATIC_MAX_TILES * 8 bytes (2 MiB) that every
- * GPU the library runs on holds until the process ends.  RTX_ERR_UNSUPPORTED for an image of more
+ * memory is allocated or freed on any path: the launch tables of the megakernel (tile costs,
+ * dispatch order, work queue) live in a static device array of RTX_STATIC_MAX_TILES * 12 bytes
+ * (3 MiB) that every GPU the library runs on holds until the process ends.  RTX_ERR_UNSUPPORTED for an image of more
  * than RTX_STATIC_MAX_TILES tiles of 8 x 8 pixels (e.g. beyond 4096 x 4096) and for the wavefront
  * variant on a scene whose BVH is deep (its path state is then a device block), and on a context
  * with collect_stats = 1 (reading counters back waits for the stream).  The call records no timing

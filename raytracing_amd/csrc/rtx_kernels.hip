@@ -349,10 +349,25 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
                 best = -1;
                 best_t = kInf;
                 bvh_always_tested<STATS>(P.bvh, tab, p.o, p.d, ray_length, all_plain, best, best_t, cnt);
+#if defined(RTX_X_REPEAT_PARTS) && ((RTX_X_REPEAT_PARTS) & 4)
+                {
+                    V3 o2 = p.o;
+                    asm volatile("" : "+v"(o2.x));
+                    bvh_always_tested<STATS>(P.bvh, tab, o2, p.d, ray_length, all_plain, best, best_t, cnt);
+                }
+#endif
                 sp = 0;
                 cur = P.bvh.n_nodes ? 0 : kBvhEmpty;
                 trav = true;
             }
+#if defined(RTX_X_REPEAT_PARTS) && ((RTX_X_REPEAT_PARTS) & 16)
+            {
+                V3 o2 = p.o;
+                asm volatile("" : "+v"(o2.x));
+                const BvhRay R2 = bvh_ray_setup(P.bvh, o2, p.d);
+                asm volatile("" : : "v"(R2.inv.x), "v"(R2.inv.y), "v"(R2.inv.z), "v"(R2.ox.x), "v"(R2.oy.y), "v"(R2.oz.x), "v"(R2.ox.y), "v"(R2.oy.x), "v"(R2.oz.y));
+            }
+#endif
             const BvhRay R = bvh_ray_setup(P.bvh, p.o, p.d);
             const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
             const uint32_t threshold = max(1u, n_active * RTX_MK_TRAV_NUM / RTX_MK_TRAV_DEN);
@@ -375,6 +390,13 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
                     MK_DBG(M_LEAF_LANES, n_leaf);
                     const bool leaves_plain = __ballot(at_leaf && !plain) == 0ull;
                     if (at_leaf) {
+#if defined(RTX_X_REPEAT_PARTS) && ((RTX_X_REPEAT_PARTS) & 2)
+                        {
+                            V3 o2 = p.o;
+                            asm volatile("" : "+v"(o2.x));
+                            bvh_try_object<STATS>(tab, ~cur, o2, p.d, ray_length, best, best_t, cnt, leaves_plain);
+                        }
+#endif
                         bvh_try_object<STATS>(tab, ~cur, p.o, p.d, ray_length, best, best_t, cnt, leaves_plain);
                         if (sp > 0) {
                             sp--;

@@ -596,6 +596,14 @@ RTX_DEV float mis_pdf(const Table &tab, V3 p, V3 n, V3 d, V3 d_unit, Counters<ST
 {
     float a = tab.n_lights == 0 ? 1.0f : 0.5f;
     float cos_pdf = rmax(dot(n, d), 0.0f) / kPi;
+#if defined(RTX_X_REPEAT_PARTS) && ((RTX_X_REPEAT_PARTS) & 1)
+    {
+        V3 p2 = p;
+        asm volatile("" : "+v"(p2.x), "+v"(d_unit.x));
+        float extra = light_pdf<STATS, MANY_LIGHTS>(tab, p2, d_unit, cnt);
+        asm volatile("" : : "v"(extra));
+    }
+#endif
     return cos_pdf * a + light_pdf<STATS, MANY_LIGHTS>(tab, p, d_unit, cnt) * (1.0f - a);
 }
 
@@ -741,6 +749,14 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
     float4 m0 = tab.mat[3 * idx + 0], m1 = tab.mat[3 * idx + 1];
     V3 color = v3(m0.x, m0.y, m0.z);
 
+#if defined(RTX_X_REPEAT_PARTS) && ((RTX_X_REPEAT_PARTS) & 8)
+    {
+        V3 o2 = p.o;
+        asm volatile("" : "+v"(o2.x), "+v"(t));
+        Hit h2 = finish_hit<MIXED>(tab, idx, o2, p.d, t, material == kDielectric);
+        asm volatile("" : : "v"(h2.n.x), "v"(h2.n.y), "v"(h2.n.z));
+    }
+#endif
     Hit h = finish_hit<MIXED>(tab, idx, p.o, p.d, t, material == kDielectric);
     V3 point = p.o + p.d * t;
     V3 n = h.n;

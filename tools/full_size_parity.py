@@ -4,7 +4,8 @@
 --full-paths: the oracle follows every path to the depth limit, as the reference does (the
 device ends paths whose throughput is zero; the image must be the same).
 c2: reference scene 1920x1080, 256 spp.  c5: glass / metal scene, depth 16, 1920x1080, 64 spp.
-c3: 10 000 objects, 960x540, 4 spp (the oracle scans every object for every ray)."""
+c3: 10 000 objects, 960x540, 4 spp (the oracle scans every object for every ray).
+c5q: c5 at 128 spp, which the device renders in chunks drawn from its work queue."""
 import os
 import sys
 import time
@@ -18,7 +19,9 @@ from raytracing_amd.renderer import Renderer
 
 threads = int(os.environ.get("OMP_NUM_THREADS", "16"))
 work = {"c2": lambda: reference_scene(1920, 1080, 256, 6), "c5": lambda: dielectric_scene(1920, 1080, 64, 16),
-        "c3": lambda: synthetic_scene(10000, 12345, 960, 540, 4, 6)}
+        "c3": lambda: synthetic_scene(10000, 12345, 960, 540, 4, 6),
+        # enough samples for the one-pixel kernels' work queue (two chunks of 60 after the 8-sample probe)
+        "c5q": lambda: dielectric_scene(1920, 1080, 128, 16)}
 ok = True
 full_paths = "--full-paths" in sys.argv
 names = [a for a in sys.argv[1:] if not a.startswith("--")]
