@@ -658,6 +658,42 @@ def test_cost_ordered_dispatch_changes_no_bits(accel):
     assert np.array_equal((state / np.float32(88)).view(np.uint32), want.view(np.uint32))
 
 
+@pytest.mark.parametrize("which", ["two_pixel_scan", "one_pixel_scan", "bvh", "bvh_many_lights"])
+def test_work_queue_of_sample_chunks_changes_no_bits(which):
+    """From 8192 tiles on, a render of enough samples is cut into chunks that waves draw from a queue in
+    device memory (a unit's chunk k + 1 waits for its chunk k and continues its sums).  A counting context
+    always renders in one plain launch, every sample of a unit in one wave: the same bits, for every kernel
+    that takes the queue, twice in a row on one context (the queue's words are reused), and continued on
+    top of an existing sum."""
+    import dataclasses
+    from raytracing_amd import synthetic_scene
+    sc = reference_scene(width=1021, height=771, n_samples=200)      # 128 x 97 tiles, ragged edges
+    accel = _abi.ACCEL_AUTO
+    if which == "one_pixel_scan":       # a coloured light: paths do not end there, the one-pixel kernel is chosen
+        prims = list(sc.prims)
+        prims[5] = dataclasses.replace(prims[5], color=(0.7, 0.7, 0.7))
+        sc = sc.replace(prims=prims)
+    elif which == "bvh":
+        sc = dielectric_scene(width=1021, height=771, n_samples=150, ray_depth=8)
+    elif which == "bvh_many_lights":
+        sc = synthetic_scene(n_prims=300, seed=5, width=1021, height=771, n_samples=136, ray_depth=4)
+    with Renderer(seed=33, accel=accel) as r:
+        first = r.render(sc)
+        again = r.render(sc)
+        r.progress_begin(sc)
+        r.progress_step(24)
+        r.progress_step(sc.n_samples - 24)     # the queue on top of an existing sum
+        continued, done = r.progress_read("mean")
+        assert done == sc.n_samples
+    with Renderer(seed=33, accel=accel, collect_stats=True) as r:
+        plain = r.render(sc)
+        assert r.stats()["samples"] == sc.width * sc.height * sc.n_samples
+    assert np.isfinite(plain).all() and plain.mean() > 0.005
+    assert np.array_equal(first.view(np.uint32), plain.view(np.uint32))
+    assert np.array_equal(again.view(np.uint32), plain.view(np.uint32))
+    assert np.array_equal(continued.view(np.uint32), plain.view(np.uint32))
+
+
 def test_device_tonemap_matches_the_host_output_stage():
     from raytracing_amd import host
     sc = reference_scene(width=160, height=120, n_samples=6)
