@@ -882,6 +882,10 @@ constexpr uint32_t kProbeSamples = RTX_PROBE_SAMPLES, kOrderedMinSamples = 64u, 
 #endif
 // work queue: fewest samples of a chunk (two-pixel kernel, one-pixel kernels), most chunks (1: no queue)
 constexpr uint32_t kChunkMin = RTX_CHUNK_MIN, kChunkMinOnePixel = RTX_CHUNK_MIN_ONE, kChunkMax = RTX_CHUNK_MAX;
+#ifndef RTX_QUEUE_TAIL
+#define RTX_QUEUE_TAIL 8192u
+#endif
+constexpr uint32_t kQueueTail = RTX_QUEUE_TAIL;   // units at the end of the order that are cut into chunks
 // the launch that follows the probe renders sample_count - kProbeSamples samples: at least one
 static_assert(kProbeSamples >= 1u && kProbeSamples < kOrderedMinSamples, "the probe must leave samples for the ordered launch");
 
@@ -1011,9 +1015,18 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
             uint32_t chunks = 1u;
             while (chunks < kChunkMax && (P.sample_count >> chunks) >= chunk_min) ++chunks;
             if (chunks > 1u) {
+                // Two-pixel kernel: only the last kQueueTail units of the order are cut into chunks -- twice what
+                // the GPU runs at once, so that their work outlasts the whole units still running when the first of
+                // them starts -- because every item costs a wave's start and end, as much as 2.8 samples of each of
+                // its pixels (reference scene, ms per frame, all units chunked / the last 16 384 / 8 192 / 6 144 /
+                // 4 096: 1080p x 256 61.3 / 61.3 / 60.5 / 60.3 / 63.9; 4K x 1024 938.5 / 922.3 / 920.2 / 920.4 / 934.1;
+                // 4K x 128 122.6 / 120.5 / 120.1 / - / 121.4).  One-pixel kernels: every unit (their order is by
+                // cost, and the glass scene measured 202.7 ms that way against 204.3 ms).
+                const uint32_t n_units = rtx::megakernel_units(P, c->src);
                 P.queue = tiles + 2u * (size_t)n_tiles;
                 P.n_chunks = chunks;
-                HIP_TRY(rtx::launch_zero_words(P.queue, 1u + (uint64_t)rtx::megakernel_units(P, c->src), stream));
+                P.n_whole = two_pixel && n_units > kQueueTail ? n_units - kQueueTail : 0u;
+                HIP_TRY(rtx::launch_zero_words(P.queue, 1u + (uint64_t)n_units, stream));
             }
         }
         HIP_TRY(rtx::launch_megakernel(P, c->src, stats, c->pool_limit, stream));

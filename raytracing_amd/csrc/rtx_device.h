@@ -93,8 +93,11 @@ struct RenderParams {
     // of that unit that are complete: a unit's chunk k + 1 continues the sums chunk k left, so it waits
     // for that count to reach k + 1.  The end of a launch is then made of short items, and the order
     // in which a pixel's samples are added does not change.  All zero before the launch.
+    // Only the end of a launch needs short items, and every item costs a wave's start and end (measured: as
+    // much as 2.8 samples of each of its pixels), so the first n_whole units of the order stay whole.
     uint32_t *queue;
     uint32_t n_chunks;
+    uint32_t n_whole;
     uint32_t ellipsoids_pow2;      // 1: every ellipsoid's radii are powers of two (kGeomPow2)
     uint32_t paths_end_at_lights;  // 1: a small all-diffuse scene whose lights are black (set at upload; picks the two-pixel scan kernel)
     uint32_t pool_entries;  // megakernel: float4 entries of a wave's hand-over pool in LDS (set by the launcher)

@@ -170,19 +170,30 @@ RTX_DEV uint32_t wave_max(uint32_t v)
 // of rays one lane of the tile's wave traced -- what the wave's running time follows.
 constexpr uint32_t kNoEntry = 0x3ffu;   // end of a list; pool entries are numbered below it
 
-// A wave's work item when the launch has a work queue (RenderParams::queue): one wave per (chunk of the
-// sample range, unit), every wave drawing a ticket.  Tickets go chunk by chunk -- all units' first chunks
-// before all second ones -- and a unit's chunks continue its pixels' sums one after the other, so a chunk
-// waits for the one before it.  Returns false for a wave beyond the last item.
+// A wave's work item when the launch has a work queue (RenderParams::queue): one wave per item, every wave
+// drawing a ticket.  The first n_whole units of the order are items of their own (all samples); the
+// others are cut into chunks of the sample range, and their tickets go chunk by chunk -- all those units'
+// first chunks before all second ones -- a unit's chunks continuing its pixels' sums one after the other,
+// so a chunk waits for the one before it.  Returns false for a wave beyond the last item.
 RTX_DEV bool queue_take_item(const RenderParams &P, uint32_t slot, uint32_t n_units, uint32_t &unit, uint32_t &chunk,
                              uint32_t &sample_first, uint32_t &sample_count, bool &accumulate)
 {
-    if (slot >= n_units * P.n_chunks) return false;
+    const uint32_t n_tail = n_units - P.n_whole;
+    if (slot >= P.n_whole + n_tail * P.n_chunks) return false;
     uint32_t ticket = 0;
     if ((threadIdx.x & 63u) == 0u) ticket = atomicAdd(P.queue, 1u);
     ticket = (uint32_t)__builtin_amdgcn_readfirstlane((int)ticket);
-    chunk = ticket / n_units;
-    unit = ticket - chunk * n_units;
+    if (ticket < P.n_whole) {
+        // the first units of the order are items of their own, all samples
+        chunk = 0;
+        unit = ticket;
+        if (P.tile_order) unit = P.tile_order[unit];
+        sample_first = P.sample_first;
+        sample_count = P.sample_count;
+        return true;
+    }
+    chunk = (ticket - P.n_whole) / n_tail;
+    unit = P.n_whole + (ticket - P.n_whole) - chunk * n_tail;
     if (P.tile_order) unit = P.tile_order[unit];
     // chunk k of n samples: [n - (n >> k), n - (n >> (k + 1))), the last one up to n
     const uint32_t lo = P.sample_count - (P.sample_count >> chunk);
@@ -949,7 +960,8 @@ hipError_t launch_megakernel(const RenderParams &p0, int src, bool stats, uint32
     const bool two = two_pixels_per_lane(p, src);
     if (stats) p.queue = nullptr;
     const uint32_t waves = two ? kScan2Block / 64u : 4u;   // per workgroup
-    const uint32_t slots = megakernel_units(p, src) * (p.queue ? p.n_chunks : 1u);   // a wave per work item
+    // a wave per work item
+    const uint32_t slots = p.queue ? p.n_whole + (megakernel_units(p, src) - p.n_whole) * p.n_chunks : megakernel_units(p, src);
     const dim3 grid((slots + waves - 1u) / waves);
     // sixteen waves share a CU's 160 KB of LDS: what the table (scan) or the traversal
     // stacks (BVH), and the parked pixel contexts of the two-pixel kernel, leave of a workgroup's
