@@ -882,6 +882,12 @@ constexpr uint32_t kProbeSamples = RTX_PROBE_SAMPLES, kOrderedMinSamples = 64u, 
 #endif
 // work queue: fewest samples of a chunk (two-pixel kernel, one-pixel kernels), most chunks (1: no queue)
 constexpr uint32_t kChunkMin = RTX_CHUNK_MIN, kChunkMinOnePixel = RTX_CHUNK_MIN_ONE, kChunkMax = RTX_CHUNK_MAX;
+#ifndef RTX_ONE_PIXEL_PLAN
+#define RTX_ONE_PIXEL_PLAN 0   // experiment: 1 = the one-pixel kernels take the two-pixel kernel's launch plan (no cost
+                               // order, only the end of the image order in chunks).  Measured: 10 000 objects 145.8 against
+                               // 140.6 ms, glass scene 210.8 against 203.5 ms (their units differ too much in cost to go
+                               // without the order), reference scene with a coloured light 87.9 against 88.8 ms
+#endif
 #ifndef RTX_QUEUE_TAIL
 #define RTX_QUEUE_TAIL 8192u
 #endif
@@ -990,7 +996,7 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
         // cost order and, with chunks of 32 samples or more, the queue as well (glass scene, 256 samples: 210 / 202 /
         // 208; 10 000 objects, 64 samples, two chunks of 28: 148 / 145 / 140 -- short chunks cost more in
         // lanes that wait at each chunk's end than the shorter end of the launch returns).
-        const bool two_pixel = probe != 0u && rtx::megakernel_two_pixels(P, c->src);
+        const bool two_pixel = probe != 0u && (RTX_ONE_PIXEL_PLAN == 1 || rtx::megakernel_two_pixels(P, c->src));
         if (two_pixel) probe = 0u;
         const uint32_t chunk_min = two_pixel ? kChunkMin : kChunkMinOnePixel;
         if (probe) {
