@@ -530,7 +530,9 @@ void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
         for (const rtx_prim &p : c->prims) fits = fits && p.material == RTX_DIFFUSE;
         for (int32_t li : c->lights) {
             const rtx_prim &p = c->prims[(size_t)li];
+#ifndef RTX_X_TWO_PIXELS_ANY_LIGHT   // timing experiment: the two-pixel kernel also where lights have a colour
             fits = fits && p.color[0] == 0.0f && p.color[1] == 0.0f && p.color[2] == 0.0f;
+#endif
         }
         P.paths_end_at_lights = fits ? 1u : 0u;
     }
