@@ -577,7 +577,6 @@ __host__ __device__ inline uint32_t scan_units(uint32_t width, uint32_t height) 
 template <int SRC, bool STATS, bool MANY_LIGHTS, bool RECORD = false, bool QUEUE = false>
 __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_scan2(const RenderParams P)
 {
-    static_assert(SRC != kSrcBvh, "the two-pixel kernel is the linear scan's");
     Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
     const uint32_t lane = threadIdx.x & 63u;
     // LDS: [object table][parked contexts of the workgroup][the waves' pools]
@@ -729,7 +728,8 @@ __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_
             cnt.template add<C_RAYS>();
             if constexpr (RECORD) rays += 1u;
             float t;
-            const int idx = closest_hit_scan<true>(tab, c.p.o, c.p.d, t);
+            // BVH scenes (small trees only, see two_pixels_per_lane): the traversal runs to its end here
+            const int idx = closest_hit<SRC, STATS>(P, tab, c.p.o, c.p.d, t, cnt);
             bool done;
             if (idx < 0) {
                 c.p.L = c.p.L + cmul(c.p.T, bg);
@@ -750,7 +750,7 @@ __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_
                         c.hit_t = t;
                         set_phase(kPhaseScatter);
                     } else {
-                        done = bounce<STATS, MANY_LIGHTS>(P, tab, c.p, idx, t, material, pixel, c.s, cnt);
+                        done = bounce<STATS, MANY_LIGHTS, SRC == kSrcBvh>(P, tab, c.p, idx, t, material, pixel, c.s, cnt);
                     }
                 }
             }
@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_
                 const uint32_t qx = unit_x - (lane & 7u) + (c.job & 7u) + 8u * ((c.job >> 6) & 1u);
                 const uint32_t qy = unit_y - (lane >> 3) + ((c.job & 63u) >> 3);
                 set_phase(kPhaseScan);
-                if (bounce<STATS, MANY_LIGHTS>(P, tab, c.p, c.hit_idx, c.hit_t, kDiffuse, qy * P.width + qx, c.s, cnt)) finish_sample();
+                if (bounce<STATS, MANY_LIGHTS, SRC == kSrcBvh>(P, tab, c.p, c.hit_idx, c.hit_t, kDiffuse, qy * P.width + qx, c.s, cnt)) finish_sample();
             }
         }
     }
@@ -941,8 +941,13 @@ static void launch_megakernel_scan2(const RenderParams &p, bool stats, dim3 grid
 // share of the CU, so that four workgroups still do.
 static bool two_pixels_per_lane(const RenderParams &p, int src)
 {
-    return RTX_MK_TWO && src != kSrcBvh && p.paths_end_at_lights != 0u &&
-           fixed_lds_bytes(p, src) + kParkVec * kScan2Block * sizeof(float4) <= 40u * 1024u * kScan2Block / 256u;
+    if (!RTX_MK_TWO || fixed_lds_bytes(p, src) + kParkVec * kScan2Block * sizeof(float4) > 40u * 1024u * kScan2Block / 256u) return false;
+#ifdef RTX_X_TWO_PIXELS_BVH   // timing experiment: small trees through the two-pixel kernel, traversals run to their end.
+    // Measured on the glass scene (27 nodes), diffuse scatter held back until 40 / 44 / 50 / 56 lanes wait for it:
+    // 236 / 248 / 261 / 290 ms against 202.5 ms for the one-pixel kernel with suspendable traversals -- not used.
+    if (src == kSrcBvh) return p.bvh.n_nodes <= 128u && p.stop_on_zero != 0u;
+#endif
+    return src != kSrcBvh && p.paths_end_at_lights != 0u;
 }
 // work units a megakernel launch deals out to its waves (and the tile cost / order tables index):
 // 8x8 tiles, or pairs of them (16x8 pixels) for the two-pixel kernel
@@ -973,6 +978,9 @@ hipError_t launch_megakernel(const RenderParams &p0, int src, bool stats, uint32
     const size_t lds = fixed + (size_t)p.pool_entries * waves * sizeof(float4);
     if (two) {
         if (src == kSrcLds) launch_megakernel_scan2<kSrcLds>(p, stats, grid, lds, stream);
+#ifdef RTX_X_TWO_PIXELS_BVH
+        else if (src == kSrcBvh) launch_megakernel_scan2<kSrcBvh>(p, stats, grid, lds, stream);
+#endif
         else launch_megakernel_scan2<kSrcScalar>(p, stats, grid, lds, stream);
     } else if (src == kSrcLds) launch_megakernel_src<kSrcLds>(p, stats, grid, lds, stream);
     else if (src == kSrcScalar) launch_megakernel_src<kSrcScalar>(p, stats, grid, lds, stream);
