@@ -93,8 +93,7 @@ struct LocalRay {
 RTX_DEV LocalRay to_local(const Geom &g, V3 o, V3 d)
 {
     LocalRay r;
-    r.o = rotate_inv(g.rot, o - g.pos);
-    r.d = rotate_inv(g.rot, d);
+    rotate_inv2(g.rot, o - g.pos, d, r.o, r.d);
     return r;
 }
 // the same for an identity-rotation object and a plain ray (see ray_is_plain)
