@@ -708,6 +708,16 @@ __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_
         const uint32_t py = unit_y - (lane >> 3) + ((c.job & 63u) >> 3);
         const uint32_t pixel = py * P.width + px;
         if (fresh) {
+#if defined(RTX_X_REPEAT_PARTS) && ((RTX_X_REPEAT_PARTS) & 32)
+            {
+                uint32_t s2 = c.s;
+                asm volatile("" : "+v"(s2));
+                uint4 w2 = draw_block(P, pixel, s2, 0u);
+                V3 o2, d2;
+                camera_ray(P, px, P.height - 1u - py, u24(w2.x), u24(w2.y), o2, d2);
+                asm volatile("" : : "v"(d2.x), "v"(d2.y), "v"(d2.z));
+            }
+#endif
             uint4 w = draw_block(P, pixel, c.s, 0u);
             camera_ray(P, px, P.height - 1u - py, u24(w.x), u24(w.y), c.p.o, c.p.d);
             c.p.T = v3(1.0f, 1.0f, 1.0f);

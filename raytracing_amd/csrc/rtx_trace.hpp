@@ -332,11 +332,70 @@ RTX_DEV void scan_category(const Table &tab, uint32_t begin, uint32_t end, V3 o,
         }
     }
 }
+// Two axis planes of one axis (the two walls of a room that face each other).  For a ray whose origin lies
+// strictly between them -- by more than 1e-30 -- the plane behind the ray is certainly rejected: its distance
+// -(o_k - p) / d_k is negative and cannot round to zero (|d_k| <= 1 up to rounding), or, for d_k = 0, minus
+// infinity; and for d_k = 0 the plane ahead gives plus infinity, which the range filter drops.  So one
+// division decides the pair: the plane ahead, chosen by the sign of d_k (for d_k = 0 either choice ends
+// without a hit).  A lane whose origin is not strictly between the planes (a ray that leaves a wall at a
+// grazing angle can start a rounding error behind it) tests both, the second in a branch that is rarely taken.
+#ifndef RTX_PLANE_PAIRS
+#define RTX_PLANE_PAIRS 1
+#endif
+template <int CAT>
+RTX_DEV void scan_axis_plane_pair(const Table &tab, uint32_t begin, V3 o, V3 d, float ray_length, int &best, float &best_t)
+{
+    const int32_t *order = tab.order + kScanHeader;
+    int ia = order[begin], ib = order[begin + 1u];
+    if (!tab.in_lds) {
+        ia = __builtin_amdgcn_readfirstlane(ia);
+        ib = __builtin_amdgcn_readfirstlane(ib);
+    }
+    const float4 pa = tab.geom[3 * ia + 1], pb = tab.geom[3 * ib + 1];
+    constexpr int k = CAT == kCatPlaneX ? 0 : (CAT == kCatPlaneY ? 1 : 2);
+    const float ok = comp(o, k), dk = comp(d, k);
+    const float na = ok - (k == 0 ? pa.x : (k == 1 ? pa.y : pa.z)), nb = ok - (k == 0 ? pb.x : (k == 1 ? pb.y : pb.z));
+    // strictly between: the two offsets have opposite signs and neither is tiny
+    const bool between = (na > 1e-30f && nb < -1e-30f) || (na < -1e-30f && nb > 1e-30f);
+    // ahead of the ray: the plane whose offset has the sign opposite to d_k's
+    const bool take_a = !between || ((na > 0.0f) != (dk > 0.0f));
+    {
+        const int i = take_a ? ia : ib;
+        float t;
+        bool hit = plane_axis_t(take_a ? na : nb, dk, t);
+        hit = hit && (t * ray_length < kInf);
+        if (hit && (t < best_t || (t == best_t && i < best))) {
+            best_t = t;
+            best = i;
+        }
+    }
+    if (__ballot(!between) != 0ull) {
+        if (!between) {
+            float t;
+            bool hit = plane_axis_t(nb, dk, t);
+            hit = hit && (t * ray_length < kInf);
+            if (hit && (t < best_t || (t == best_t && ib < best))) {
+                best_t = t;
+                best = ib;
+            }
+        }
+    }
+}
+
 template <int CAT>
 RTX_DEV void scan_categories_from(const Table &tab, const uint32_t (&ends)[kScanHeader], uint32_t begin, V3 o, V3 d,
                                   float ray_length, int &best, float &best_t)
 {
     if constexpr (CAT < kScanCats) {
+#if RTX_PLANE_PAIRS
+        if constexpr (CAT == kCatPlaneX || CAT == kCatPlaneY || CAT == kCatPlaneZ) {
+            if (ends[CAT] - begin == 2u) {
+                scan_axis_plane_pair<CAT>(tab, begin, o, d, ray_length, best, best_t);
+                scan_categories_from<CAT + 1>(tab, ends, ends[CAT], o, d, ray_length, best, best_t);
+                return;
+            }
+        }
+#endif
         scan_category<CAT>(tab, begin, ends[CAT], o, d, ray_length, best, best_t);
 #ifdef RTX_X_REPEAT_CATS   // timing experiment: the categories of this bit mask run twice
         if constexpr (((RTX_X_REPEAT_CATS) >> CAT) & 1) {

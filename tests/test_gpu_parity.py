@@ -527,7 +527,10 @@ def test_axis_planes_through_the_ray_origin_or_parallel_to_the_ray(oracle):
     (distance inf or NaN) and normals of either sign must leave the oracle's bits, for random and
     for constant draw words (the latter put a whole pixel column on d.x = 0)."""
     from raytracing_amd import Prim
-    cams = [(0.0, -5.0, 15.0), (5.0, 0.0, 15.0), (-5.0, 5.0, 4.0), (0.0, 0.0, -5.0), (0.0, 0.0, 15.0)]
+    # the two planes of an axis that face each other are tested with one division when the origin lies
+    # strictly between them: origins on one of them, between them and outside both (the last two cameras)
+    cams = [(0.0, -5.0, 15.0), (5.0, 0.0, 15.0), (-5.0, 5.0, 4.0), (0.0, 0.0, -5.0), (0.0, 0.0, 15.0), (0.0, 7.0, 15.0),
+            (-8.0, -6.5, 3.0)]
     for cam in cams:
         for words in (None, (0, 0, 0, 0)):
             sc = reference_scene(width=34, height=18, n_samples=3).replace(cam_pos=cam)
