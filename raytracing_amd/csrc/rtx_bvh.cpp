@@ -9,6 +9,13 @@
 #include <limits>
 #include <queue>
 
+#ifndef RTX_BVH_SWEEP_MAX
+#define RTX_BVH_SWEEP_MAX 65536
+#endif
+#ifndef RTX_BVH_OPT_PASSES
+#define RTX_BVH_OPT_PASSES 3
+#endif
+
 namespace rtx {
 namespace {
 
@@ -116,6 +123,8 @@ int ceil_log2(size_t n)
     return k;
 }
 
+constexpr size_t kSweepMax = RTX_BVH_SWEEP_MAX;
+
 struct Builder {
     std::vector<Ref> refs;
     std::vector<BuildNode> nodes;
@@ -153,8 +162,43 @@ struct Builder {
         return mid;
     }
 
+    // Exact surface-area heuristic: every partition of the centres' order along every axis is priced.
+    // O(n log n) per call, used below kSweepMax objects.
+    size_t split_sweep(size_t b, size_t e)
+    {
+        const size_t n = e - b;
+        double best_cost = std::numeric_limits<double>::infinity();
+        int best_axis = -1;
+        size_t best_k = 0;
+        std::vector<double> right(n);
+        for (int axis = 0; axis < 3; ++axis) {
+            std::sort(refs.begin() + (ptrdiff_t)b, refs.begin() + (ptrdiff_t)e, [axis](const Ref &x, const Ref &y) {
+                return x.c[axis] < y.c[axis] || (x.c[axis] == y.c[axis] && x.prim < y.prim);
+            });
+            Box3 acc;
+            acc.clear();
+            for (size_t i = n - 1; i > 0; --i) {
+                acc.grow(refs[b + i].box);
+                right[i] = acc.half_area();
+            }
+            acc.clear();
+            for (size_t i = 0; i + 1 < n; ++i) {
+                acc.grow(refs[b + i].box);
+                const double cost = acc.half_area() * (double)(i + 1) + right[i + 1] * (double)(n - i - 1);
+                if (cost < best_cost) { best_cost = cost; best_axis = axis; best_k = i + 1; }
+            }
+        }
+        if (best_axis < 0) return split_median(b, e);
+        if (best_axis != 2)
+            std::sort(refs.begin() + (ptrdiff_t)b, refs.begin() + (ptrdiff_t)e, [best_axis](const Ref &x, const Ref &y) {
+                return x.c[best_axis] < y.c[best_axis] || (x.c[best_axis] == y.c[best_axis] && x.prim < y.prim);
+            });
+        return b + best_k;
+    }
+
     size_t split(size_t b, size_t e)
     {
+        if (e - b <= kSweepMax) return split_sweep(b, e);
         Box3 cb;
         cb.clear();
         for (size_t i = b; i < e; ++i)
@@ -212,6 +256,127 @@ struct Builder {
         // all centres coincide (or binning failed): split by object index
         if (mid == b || mid == e) mid = split_median(b, e);
         return mid;
+    }
+};
+
+// The tree as the optimiser below wants it: every node with its own box and a link to its parent.
+struct TreeNode {
+    Box3 box;
+    int32_t parent = -1;
+    int32_t child[2] = {-1, -1};   // inner node: both >= 0
+    int32_t prim = -1;             // leaf: the object
+    bool leaf() const { return child[0] < 0; }
+};
+
+// Insertion-based optimisation of a finished tree (after Bittner, Hapala and Havran, "Fast insertion-based
+// optimization of bounding volume hierarchies", 2013): a subtree is taken out -- its parent disappears, its
+// sibling moves up -- and put back as the sibling of whichever node lowers the summed surface area of the inner
+// nodes most.  The search walks up from the old position and, at every level, down into the subtree that hangs
+// off the path, with the area saved so far as its budget (branch and bound).  The tree's leaves, and with them
+// every result of a traversal, stay what they are; only the number of node visits changes.
+struct TreeOptimizer {
+    std::vector<TreeNode> &t;
+    int32_t root;
+    std::vector<std::pair<double, int32_t>> stack;
+
+    int32_t other_child(int32_t parent, int32_t c) const { return t[(size_t)parent].child[0] == c ? t[(size_t)parent].child[1] : t[(size_t)parent].child[0]; }
+    void refit_upwards(int32_t i)
+    {
+        for (; i >= 0; i = t[(size_t)i].parent) {
+            Box3 b = t[(size_t)t[(size_t)i].child[0]].box;
+            b.grow(t[(size_t)t[(size_t)i].child[1]].box);
+            t[(size_t)i].box = b;
+        }
+    }
+    // best new sibling for node `in` and the area it saves (<= 0: leave it where it is)
+    std::pair<int32_t, double> find(int32_t in)
+    {
+        const Box3 in_box = t[(size_t)in].box;
+        const double in_area = in_box.half_area();
+        const int32_t parent = t[(size_t)in].parent;
+        double budget = t[(size_t)parent].box.half_area();   // the parent disappears
+        int32_t sibling = other_child(parent, in), pivot = parent;
+        Box3 pivot_box = t[(size_t)sibling].box;                // the pivot's box once `in` is gone
+        int32_t best = -1;
+        double best_gain = 0.0;
+        for (;;) {
+            stack.clear();
+            stack.emplace_back(budget, sibling);
+            while (!stack.empty()) {
+                const double b = stack.back().first;
+                const int32_t dst = stack.back().second;
+                stack.pop_back();
+                if (b - in_area <= best_gain) continue;       // even a perfect fit cannot beat the best
+                Box3 m = t[(size_t)dst].box;
+                m.grow(in_box);
+                const double gain = b - m.half_area();          // the new inner node costs its area
+                if (gain > best_gain) { best = dst; best_gain = gain; }
+                if (!t[(size_t)dst].leaf()) {
+                    // below dst: dst grows to m
+                    const double below = gain + t[(size_t)dst].box.half_area();
+                    stack.emplace_back(below, t[(size_t)dst].child[0]);
+                    stack.emplace_back(below, t[(size_t)dst].child[1]);
+                }
+            }
+            if (pivot == root) break;
+            if (pivot != parent) {
+                pivot_box.grow(t[(size_t)sibling].box);
+                budget += t[(size_t)pivot].box.half_area() - pivot_box.half_area();   // the pivot shrinks
+            }
+            sibling = other_child(t[(size_t)pivot].parent, pivot);
+            pivot = t[(size_t)pivot].parent;
+        }
+        return {best, best_gain};
+    }
+    void move(int32_t in, int32_t out)
+    {
+        const int32_t parent = t[(size_t)in].parent, up = t[(size_t)parent].parent;
+        const int32_t sibling = other_child(parent, in);
+        // the sibling takes the parent's place
+        t[(size_t)up].child[t[(size_t)up].child[0] == parent ? 0 : 1] = sibling;
+        t[(size_t)sibling].parent = up;
+        // the freed node becomes the parent of `out` and `in`, where `out` was
+        const int32_t above = t[(size_t)out].parent;
+        t[(size_t)above].child[t[(size_t)above].child[0] == out ? 0 : 1] = parent;
+        t[(size_t)parent].parent = above;
+        t[(size_t)parent].child[0] = out;
+        t[(size_t)parent].child[1] = in;
+        t[(size_t)out].parent = parent;
+        t[(size_t)in].parent = parent;
+        refit_upwards(up);
+        refit_upwards(parent);
+    }
+    // One pass over all nodes, largest first.  Returns the area saved.
+    double pass()
+    {
+        std::vector<std::pair<double, int32_t>> order;
+        for (size_t i = 0; i < t.size(); ++i)
+            if ((int32_t)i != root && t[i].parent != root) order.emplace_back(-t[i].box.half_area(), (int32_t)i);
+        std::sort(order.begin(), order.end());
+        double saved = 0.0;
+        for (const auto &o : order) {
+            const int32_t in = o.second;
+            if (t[(size_t)in].parent == root) continue;   // moved there meanwhile
+            const auto r = find(in);
+            if (r.first < 0 || !(r.second > 1e-9 * t[(size_t)root].box.half_area())) continue;
+            move(in, r.first);
+            saved += r.second;
+        }
+        return saved;
+    }
+    int depth_below(int32_t i) const
+    {
+        // iterative: the tree may be deep
+        int deepest = 0;
+        std::vector<std::pair<int32_t, int>> todo{{i, 0}};
+        while (!todo.empty()) {
+            const auto [n, d] = todo.back();
+            todo.pop_back();
+            if (t[(size_t)n].leaf()) { deepest = std::max(deepest, d); continue; }
+            todo.emplace_back(t[(size_t)n].child[0], d + 1);
+            todo.emplace_back(t[(size_t)n].child[1], d + 1);
+        }
+        return deepest;
     }
 };
 
@@ -330,6 +495,57 @@ void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
         nd.ref[1] = kBvhEmpty;
         bld.nodes.push_back(nd);
         root = (int32_t)bld.nodes.size() - 1;
+    }
+    if (RTX_BVH_OPT_PASSES > 0 && bld.refs.size() >= 8) {
+        // the same tree with parent links, optimised, and written back if it still fits the depth limit
+        std::vector<TreeNode> t;
+        t.reserve(2 * bld.refs.size());
+        std::vector<Box3> prim_box(n);
+        for (const Ref &r : bld.refs) prim_box[(size_t)r.prim] = r.box;
+        struct Item { int32_t ref, parent; int slot; };
+        std::vector<Item> todo{{root, -1, 0}};
+        while (!todo.empty()) {
+            const Item it = todo.back();
+            todo.pop_back();
+            const int32_t me = (int32_t)t.size();
+            t.emplace_back();
+            t[(size_t)me].parent = it.parent;
+            if (it.parent >= 0) t[(size_t)it.parent].child[it.slot] = me;
+            if (it.ref < 0) {
+                t[(size_t)me].prim = ~it.ref;
+                t[(size_t)me].box = prim_box[(size_t)~it.ref];
+            } else {
+                const BuildNode &nd = bld.nodes[(size_t)it.ref];
+                t[(size_t)me].box = nd.box[0];
+                if (nd.ref[1] != kBvhEmpty) t[(size_t)me].box.grow(nd.box[1]);
+                todo.push_back({nd.ref[0], me, 0});
+                todo.push_back({nd.ref[1], me, 1});
+            }
+        }
+        TreeOptimizer opt{t, 0, {}};
+        const double root_area = t[0].box.half_area();
+        for (int pass = 0; pass < RTX_BVH_OPT_PASSES; ++pass)
+            if (!(opt.pass() > 1e-4 * root_area)) break;
+        const int depth = opt.depth_below(0);
+        if (depth < kBvhMaxDepth) {
+            // back into build nodes, the root first
+            std::vector<BuildNode> nodes;
+            std::vector<int32_t> index(t.size(), -1);
+            for (size_t i = 0; i < t.size(); ++i)
+                if (!t[i].leaf()) { index[i] = (int32_t)nodes.size(); nodes.emplace_back(); }
+            for (size_t i = 0; i < t.size(); ++i) {
+                if (t[i].leaf()) continue;
+                BuildNode &nd = nodes[(size_t)index[i]];
+                for (int c = 0; c < 2; ++c) {
+                    const TreeNode &ch = t[(size_t)t[i].child[c]];
+                    nd.box[c] = ch.box;
+                    nd.ref[c] = ch.leaf() ? ~ch.prim : index[(size_t)t[i].child[c]];
+                }
+            }
+            bld.nodes.swap(nodes);
+            bld.depth = depth;
+            root = 0;
+        }
     }
     // breadth-first renumbering
     std::vector<int32_t> order, new_index(bld.nodes.size(), -1);
