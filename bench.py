@@ -8,7 +8,9 @@ the per-GPU radiance sums added and divided by the sample count.  The scene and 
 are resident in HBM before the timed region starts.
 
 The headline workload is the same for every N: c4, the reference scene at 3840x2160, 1024 spp,
-its samples split over the N GPUs (fixed total work: "scaling": "strong").  Two drivers of the split:
+the frame dealt out to the N GPUs in small blocks of pixels, round-robin (fixed total work: "scaling":
+"strong"; every pixel's samples are traced and added on one GPU, so the image has the bits of a one-GPU
+render).  Two drivers of the split:
 
   * one process, several GPUs (the plain command above, no launcher): the library's own multi-GPU
     path -- rtx_opts.n_devices = N, one worker and stream per GPU inside librtx.so, the sums added by
@@ -16,8 +18,8 @@ its samples split over the N GPUs (fixed total work: "scaling": "strong").  Two 
     device buffer of the first GPU (rtx_render_device).  --devices 0,0,0 names the ordinals (an
     ordinal may repeat: a rehearsal of N workers on one GPU).
   * one process per GPU (under `python -m torch.distributed.run --nproc-per-node N`; WORLD_SIZE is
-    set): rank g renders its sample range with rtx_render_samples, one all_reduce(SUM) over RCCL,
-    rtx_divide.
+    set): rank g takes share g of N (rtx_set_share), rtx_render_samples, one all_reduce(SUM) over RCCL of
+    buffers that are zero outside their share, rtx_divide.
 
 With no --workload and N = 1 the line also carries, under "workloads", the other configurations
 (timed the same way): c2 with its full roofline and counters, c3 and c5 with both kernels, c2 with
@@ -49,7 +51,7 @@ def build_workload(name, spp_override=None, size_override=None):
     if name == "c2":
         sc, desc = reference_scene(1920, 1080, 256, 6), "reference scene (8 objects, 1 light), 1920x1080, 256 spp, depth 6"
     elif name == "c4":
-        sc, desc = reference_scene(3840, 2160, 1024, 6), "reference scene (8 objects, 1 light), 3840x2160, 1024 spp, depth 6, spp split over the GPUs"
+        sc, desc = reference_scene(3840, 2160, 1024, 6), "reference scene (8 objects, 1 light), 3840x2160, 1024 spp, depth 6, the frame dealt out to the GPUs"
     elif name == "c3":
         sc, desc = synthetic_scene(10000, 12345, 1920, 1080, 64, 6), "synthetic 10k objects (8 lights), 1920x1080, 64 spp, depth 6, BVH"
     elif name == "c5":
@@ -176,7 +178,6 @@ def measure(name, mode_name, accel_name, steps, warmup, seed, run, want_stats=Tr
     from raytracing_amd.renderer import Renderer
     from raytracing_amd.flops import (algorithmic_flops, elided_flops, executed_flops, PEAK_FP32_VECTOR_TFLOPS,
                                       PEAK_FP32_NONPACKED_TFLOPS)
-    from raytracing_amd.parallel import sample_range
 
     scene, desc = build_workload(name, spp, size)
     if depth is not None:
@@ -201,8 +202,10 @@ def measure(name, mode_name, accel_name, steps, warmup, seed, run, want_stats=Tr
                         collect_stats=collect_stats)
 
     r = context()
+    if ranks:
+        r.set_share(rank, world)   # this rank's share of the frame's work units, every sample of them
     r.set_scene(scene)
-    first, count = sample_range(scene.n_samples, rank, world) if ranks else (0, scene.n_samples)
+    first, count = 0, scene.n_samples
     kernel_times = []
 
     def step(timed=False):
@@ -343,7 +346,7 @@ def main():
         # the process group is always created, so the RCCL path is the one exercised even with a single rank
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         run = {"driver": "ranks", "world": world, "rank": rank, "device": local_rank, "use_dist": True}
-        parallelism = f"one process per GPU x{world}: spp split + RCCL all-reduce (torch.distributed)" if world > 1 else "one process, one GPU (RCCL all-reduce of one rank)"
+        parallelism = f"one process per GPU x{world}: the frame's work units dealt out round-robin (rtx_set_share) + RCCL all-reduce (torch.distributed)" if world > 1 else "one process, one GPU (RCCL all-reduce of one rank)"
         visible = torch.cuda.device_count()
     else:
         # one process: the library's own multi-GPU path
@@ -360,7 +363,7 @@ def main():
         reduce = {"p2p": _abi.REDUCE_P2P, "rccl": _abi.REDUCE_RCCL}[args.reduce]
         run = {"driver": "library", "world": 1, "rank": 0, "devices": devices, "reduce": reduce, "use_dist": False}
         world, rank = args.gpus, 0
-        parallelism = (f"one process, rtx_opts.n_devices = {world}: spp split over {len(set(devices))} GPU(s), {args.reduce} reduce in librtx"
+        parallelism = (f"one process, rtx_opts.n_devices = {world}: the frame's work units dealt out round-robin over {len(set(devices))} GPU(s), {args.reduce} reduce in librtx"
                        if world > 1 or args.reduce == "rccl" else "single GPU")
 
     name = args.workload or "c4"

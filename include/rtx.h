@@ -14,8 +14,8 @@
  * RTX_OK (0) or a negative rtx_status, and rtx_last_error() gives a message for
  * the calling thread's last failure.  One rtx_ctx belongs to one host thread at
  * a time.  It drives one GPU, or -- rtx_opts.n_devices > 1 -- several GPUs of one
- * node from that one thread: the sample loop is split over them and their sums are
- * added on the devices (see rtx_opts).  Renders of one context share device scratch
+ * node from that one thread: the frame is dealt out to them in small blocks of pixels and
+ * put together on the devices (see rtx_opts).  Renders of one context share device scratch
  * (path state, tile order): give them one stream, or wait for one to end before the
  * next starts on another stream; rtx_set_scene waits for the context's device(s) to
  * go idle before it overwrites the scene a render may still be reading.
@@ -110,14 +110,15 @@ typedef struct rtx_opts {
     uint32_t const_words[4];
     int32_t device;          /* HIP device ordinal; -1 = the current device (used when n_devices <= 1) */
     uint32_t collect_stats;  /* 1 = count path events (slower kernels; see rtx_get_stats) */
-    /* Several GPUs behind one context.  The loop over sample steps (src/main.rs:14) is cut into
-     * n_devices contiguous ranges, GPU g renders range g of every pixel into its own sum buffer on
-     * its own stream, and the sums are added as `reduce` says -- all inside rtx_render,
-     * rtx_render_device, rtx_render_bytes and rtx_progress_*, which keep their signatures.  The
-     * image of a one-shot render depends on n_devices only through the order of these n_devices
-     * additions per value (progressive renders: see rtx_progress_*).
+    /* Several GPUs behind one context.  The frame is cut into the kernels' work units (blocks of
+     * 8 x 8 or 16 x 8 pixels, or a few consecutive ones), dealt out round-robin: GPU g renders every
+     * sample step (src/main.rs:14) of units g, g + n_devices, ... into its own sum buffer, which is
+     * zero elsewhere, on its own stream, and the buffers are added as `reduce` says -- all inside
+     * rtx_render, rtx_render_device, rtx_render_bytes and rtx_progress_*, which keep their
+     * signatures.  A pixel's samples are traced and added on one GPU, in order, and adding zeros
+     * changes nothing: the image has the bits of a one-GPU render whatever n_devices is.
      * n_devices 0 or 1: one GPU, `device`.  devices = NULL: ordinals 0 .. n_devices-1.  An ordinal
-     * may repeat (several ranges on one GPU; RTX_REDUCE_P2P only).  Entry points that take DEVICE
+     * may repeat (several shares on one GPU; RTX_REDUCE_P2P only).  Entry points that take DEVICE
      * pointers (rtx_render_samples, rtx_accumulate_samples, rtx_divide, rtx_tonemap_bytes) and
      * rtx_primary run on devices[0] alone. */
     int32_t n_devices;
@@ -166,9 +167,23 @@ int rtx_render(rtx_ctx *ctx, const rtx_scene *scene, float *rgb);
  * [sample_first, sample_first + sample_count) of the scene given to
  * rtx_set_scene.  Writes (not adds) the per-pixel SUM of radiance to d_sum, a
  * DEVICE buffer of width*height*3 floats, asynchronously on hip_stream
- * (a hipStream_t; NULL = the null stream).  Used to split samples over GPUs. */
+ * (a hipStream_t; NULL = the null stream).  Used to cut the loop into steps, and -- with
+ * rtx_set_share -- to spread a frame over the GPUs of several processes. */
 int rtx_render_samples(rtx_ctx *ctx, uint32_t sample_first, uint32_t sample_count,
                        float *d_sum, void *hip_stream);
+
+/* One process per GPU: share `share_index` of `share_count` of every frame.  No counterpart in
+ * the reference (its loop runs in one process).  From this call on rtx_render_samples and
+ * rtx_render_samples_static write the sums of this share's pixels -- the kernels' work units
+ * share_index, share_index + share_count, ... (blocks of 8 x 8 or 16 x 8 pixels, or a few consecutive
+ * ones, depending on the kernel chosen for the scene) -- and ZERO everywhere else, and
+ * rtx_accumulate_samples continues this share's pixels and leaves the others as they are.  The
+ * share_count buffers of contexts with the same options and scene, added up (an all-reduce), are
+ * the frame, with the bits of one context rendering it alone: every pixel's samples are traced
+ * and added by one share, in order.  rtx_get_stats then counts this share's events, and the
+ * counters of all shares add up to the one-context numbers.  (0, 1) = the whole frame, the
+ * default.  RTX_ERR_UNSUPPORTED on a multi-GPU context, which deals the frame out itself. */
+int rtx_set_share(rtx_ctx *ctx, uint32_t share_index, uint32_t share_count);
 
 /* rtx_render_samples for callers that cannot allocate device memory: code under HIP graph
  * capture, tight serving loops, harnesses that forbid hipMalloc.  It has no counterpart in the
@@ -210,7 +225,7 @@ int rtx_tonemap_bytes(rtx_ctx *ctx, const float *d_sum, uint64_t n_floats, float
 /* rtx_render (src/main.rs:13-31) with the image left on the device: renders n_samples samples per
  * pixel of the scene given to rtx_set_scene and writes the mean linear radiance to d_rgb, a DEVICE
  * buffer of width*height*3 floats (row 0 = top) on the context's first GPU, which the caller has
- * finished writing to.  A multi-GPU context splits the samples, and GPU g adds slice g of all sums,
+ * finished writing to.  A multi-GPU context deals the frame out, and GPU g adds slice g of all sums,
  * divides and writes that slice straight into d_rgb (peer access), or -- RTX_REDUCE_RCCL -- the
  * first GPU copies the all-reduced image there.  Same bits as rtx_render.  Returns when the image
  * is complete. */
@@ -229,12 +244,11 @@ int rtx_render_bytes(rtx_ctx *ctx, const rtx_scene *scene, uint8_t *bytes);
  *   step:  render the next sample_count samples onto the sum; returns when done.
  *   read:  any of rgb_mean (sum / samples, what rtx_render returns), sum (the state to
  *          save), bytes (tone-mapped, as rtx_render_bytes) and samples_done may be NULL.
- * On a single-GPU context, after begin + steps totalling n samples, read returns the bits of
- * rtx_render with n_samples = n, however the steps were cut and wherever a save / resume happened.
- * On a multi-GPU context every step is split over the GPUs again and a resumed sum continues on
- * the first one, so the order of a value's additions -- and with it the last bits of the result
- * (<= 1e-6 relative) -- depends on the step cuts.  read adds the GPUs' sums once, whatever
- * combination of outputs is asked for.
+ * After begin + steps totalling n samples, read returns the bits of rtx_render with n_samples = n,
+ * however the steps were cut, wherever a save / resume happened and however many GPUs the context
+ * drives: a resumed sum continues, pixel by pixel, on the GPU that owns the pixel.  (One exception:
+ * a saved value of -0 comes back from a multi-GPU context as +0.)  read adds the GPUs' buffers
+ * once, whatever combination of outputs is asked for.
  * rtx_render, rtx_render_device and rtx_render_bytes on the same context end the progressive render. */
 int rtx_progress_begin(rtx_ctx *ctx, const rtx_scene *scene, const float *sum, uint32_t samples_done);
 int rtx_progress_step(rtx_ctx *ctx, uint32_t sample_count);
@@ -275,7 +289,7 @@ const char *rtx_last_error(void);
 
 /* ABI version of this header: bumped on any layout or signature change. */
 uint32_t rtx_abi_version(void);
-#define RTX_ABI_VERSION 4u
+#define RTX_ABI_VERSION 5u
 
 #ifdef __cplusplus
 }

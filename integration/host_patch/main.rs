@@ -2,7 +2,7 @@
 // `render` replaces main.rs:13-31; `main` (main.rs:33-42) stays as it is: parse_scene, render,
 // color_correction, write.  `use rand::Rng;` and `use trace::trace_ray;` (main.rs:10-11) go.
 
-/// GPUs to split the samples over: RTX_GPUS=N in the environment, default 1.
+/// GPUs to deal the frame out to: RTX_GPUS=N in the environment, default 1.
 fn gpu_count() -> i32 {
     std::env::var("RTX_GPUS").ok().and_then(|s| s.parse().ok()).unwrap_or(1)
 }
@@ -31,6 +31,6 @@ fn render(scene: &mut Scene) {
     let mut ctx = rtx_sys::Context::new(&opts).unwrap_or_else(|e| panic!("rtx_create: {e}"));
     let pixels = scene.image.data_mut();
     let rgb = unsafe { std::slice::from_raw_parts_mut(pixels.as_mut_ptr() as *mut f32, pixels.len() * 3) };
-    // splits the samples over the GPUs, adds their sums on the devices, divides, copies back
+    // deals the frame out to the GPUs, adds their buffers on the devices, divides, copies back
     ctx.render(&pod, &scene.pod, rgb).unwrap_or_else(|e| panic!("rtx_render: {e}"));
 }

@@ -8,7 +8,7 @@
 use std::ffi::CStr;
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const RTX_ABI_VERSION: u32 = 4;
+pub const RTX_ABI_VERSION: u32 = 5;
 
 pub const RTX_OK: c_int = 0;
 pub const RTX_ERR_INVALID_ARG: c_int = -1;
@@ -121,6 +121,7 @@ extern "C" {
     pub fn rtx_render_device(ctx: *mut rtx_ctx, n_samples: u32, d_rgb: *mut f32) -> c_int;
     pub fn rtx_render_samples(ctx: *mut rtx_ctx, sample_first: u32, sample_count: u32, d_sum: *mut f32, hip_stream: *mut c_void) -> c_int;
     pub fn rtx_render_samples_static(ctx: *mut rtx_ctx, sample_first: u32, sample_count: u32, d_sum: *mut f32, hip_stream: *mut c_void) -> c_int;
+    pub fn rtx_set_share(ctx: *mut rtx_ctx, share_index: u32, share_count: u32) -> c_int;
     pub fn rtx_accumulate_samples(ctx: *mut rtx_ctx, sample_first: u32, sample_count: u32, d_sum: *mut f32, hip_stream: *mut c_void) -> c_int;
     pub fn rtx_divide(ctx: *mut rtx_ctx, d_rgb: *mut f32, n_floats: u64, divisor: f32, hip_stream: *mut c_void) -> c_int;
     pub fn rtx_tonemap_bytes(ctx: *mut rtx_ctx, d_sum: *const f32, n_floats: u64, divisor: f32, d_bytes: *mut u8, hip_stream: *mut c_void) -> c_int;
@@ -150,7 +151,7 @@ pub struct Context {
 }
 
 impl Context {
-    /// All `n` GPUs 0..n of the node behind one context: `render` splits the samples over them.
+    /// All `n` GPUs 0..n of the node behind one context: `render` deals the frame out to them (same bits as one GPU).
     pub fn with_gpus(n: i32, seed: u64) -> Result<Context, String> {
         let opts = rtx_opts { seed, n_devices: n, ..Default::default() };
         Context::new(&opts)

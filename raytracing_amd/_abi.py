@@ -22,7 +22,7 @@ RTX_ERR_NO_SCENE = -4
 RTX_ERR_UNSUPPORTED = -5
 RTX_ERR_NO_MEMORY = -6
 
-RTX_ABI_VERSION = 4
+RTX_ABI_VERSION = 5
 RTX_MAX_LDS_PRIMS = 512
 RTX_MAX_DEVICES = 16
 RTX_STATIC_MAX_TILES = 262144

@@ -200,13 +200,15 @@ struct rtx_ctx {
     size_t d_tiles_words = 0;
     uint32_t *static_tiles = nullptr;   // device address of this GPU's `scratch`
     uint32_t pool_limit = rtx::kPoolEntriesMax;   // cap of the megakernel's hand-over pool (RTX_POOL_ENTRIES)
+    // this context's share of every frame (rtx_set_share; the workers of a multi-GPU context: worker g of G)
+    uint32_t share_index = 0, share_count = 1;
     unsigned long long *d_stats = nullptr;
     rtx_stats stats{};
     bool stats_valid = false;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     bool timed = false;
     // A multi-GPU context is its own worker 0 and owns one more context per further GPU.  Every
-    // worker renders its share of the samples into its d_image on its own stream.
+    // worker renders its share of the frame's work units into its d_image on its own stream.
     std::vector<rtx_ctx *> peers;
     hipStream_t stream = nullptr;   // workers of a multi-GPU context: their own stream
     hipEvent_t ev_done = nullptr;   // this worker's share of a render is complete
@@ -770,6 +772,13 @@ int rtx_create(rtx_ctx **out, const rtx_opts *opts)
             if (rc != RTX_OK) { rtx_destroy(c); return rc; }
             c->peers.push_back(p);
         }
+        {
+            std::vector<rtx_ctx *> ws = workers_of(c);
+            for (size_t i = 0; i < ws.size(); ++i) {
+                ws[i]->share_index = (uint32_t)i;
+                ws[i]->share_count = (uint32_t)ws.size();
+            }
+        }
         if (devs.size() > 1 && opts->reduce == RTX_REDUCE_P2P) {
             // every GPU reads its slice from every other GPU's buffer
             for (size_t i = 0; i < devs.size(); ++i) {
@@ -897,6 +906,13 @@ constexpr uint32_t kQueueTail = RTX_QUEUE_TAIL;   // units at the end of the ord
 // the launch that follows the probe renders sample_count - kProbeSamples samples: at least one
 static_assert(kProbeSamples >= 1u && kProbeSamples < kOrderedMinSamples, "the probe must leave samples for the ordered launch");
 
+// how the kernel this context launches for its scene cuts the frame into work units
+rtx::UnitShape unit_shape_of(const rtx_ctx *c)
+{
+    if (c->opts.mode == RTX_MODE_WAVEFRONT) return rtx::UnitShape{0u, rtx::wavefront_group_tiles(c->params, c->src)};
+    return rtx::megakernel_unit_shape(c->params, c->src);
+}
+
 // `no_alloc`: the caller may not allocate device memory -- the tile tables are this GPU's static
 // ones, and whatever would need a fresh block is refused.
 int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream,
@@ -914,6 +930,8 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
     P.sample_count = sample_count;
     P.out_sum = d_sum;
     P.accumulate = accumulate ? 1u : 0u;
+    P.share_index = c->share_index;
+    P.share_count = c->share_count;
     const bool stats = c->opts.collect_stats != 0;
     P.stats = stats ? c->d_stats : nullptr;
     c->stats_valid = false;
@@ -951,6 +969,10 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
     }
     if (stats) HIP_TRY(hipMemsetAsync(c->d_stats, 0, rtx::C_COUNT * sizeof(unsigned long long), stream));
     if (timed) HIP_TRY(hipEventRecord(c->ev_start, stream));
+    // A share of the frame: the kernels write this share's pixels only, and a fresh sum is zero everywhere
+    // else, so that the shares of a job add up to the frame.  (A kernel, not a memset: see the tile tables.)
+    if (P.share_count > 1u && !accumulate)
+        HIP_TRY(rtx::launch_zero_words(reinterpret_cast<uint32_t *>(d_sum), (uint64_t)P.width * P.height * 3u, stream));
     if (c->opts.mode == RTX_MODE_WAVEFRONT) {
         rtx::WfState S;
         S.rec = nullptr;
@@ -975,7 +997,7 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
         // chunks that waves draw from a queue, so that the last items to run are short.
         uint32_t probe = 0;
         uint32_t *tiles = nullptr;
-        if (!stats && sample_count >= kOrderedMinSamples && n_tiles >= kOrderedMinTiles) {
+        if (!stats && sample_count >= kOrderedMinSamples && rtx::share_units(n_tiles, P.share_index, P.share_count) >= kOrderedMinTiles) {
             probe = kProbeSamples;
             if (no_alloc) {
                 tiles = c->static_tiles;
@@ -1031,9 +1053,10 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
                 // 4K x 128 122.6 / 120.5 / 120.1 / - / 121.4).  One-pixel kernels: every unit (their order is by
                 // cost, and the glass scene measured 202.7 ms that way against 204.3 ms).
                 const uint32_t n_units = rtx::megakernel_units(P, c->src);
+                const uint32_t n_own = rtx::share_units(n_units, P.share_index, P.share_count);
                 P.queue = tiles + 2u * (size_t)n_tiles;
                 P.n_chunks = chunks;
-                P.n_whole = two_pixel && n_units > kQueueTail ? n_units - kQueueTail : 0u;
+                P.n_whole = two_pixel && n_own > kQueueTail ? n_own - kQueueTail : 0u;
                 HIP_TRY(rtx::launch_zero_words(P.queue, 1u + (uint64_t)n_units, stream));
             }
         }
@@ -1051,10 +1074,11 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
     return RTX_OK;
 }
 
-// ---- a multi-GPU context: the sample loop cut over the workers, sums added on the devices ----
+// ---- a multi-GPU context: the frame's work units dealt out to the workers, sums added on the devices ----
 
-// Worker g renders its share of samples [first, first + count) onto (accumulate) or into its own
-// d_image, on its own stream; ev_done marks the end of its share.  Returns without waiting.
+// Worker g renders samples [first, first + count) of its share of the frame's work units onto
+// (accumulate) or into its own d_image, on its own stream; ev_done marks the end of its share.
+// Returns without waiting.
 int render_shares(rtx_ctx *c, uint32_t first, uint32_t count, bool accumulate)
 {
     std::vector<rtx_ctx *> ws = workers_of(c);
@@ -1066,9 +1090,7 @@ int render_shares(rtx_ctx *c, uint32_t first, uint32_t count, bool accumulate)
         if (!dg.ok) return fail(RTX_ERR_DEVICE, "cannot select device %d", w->device);
         int rc = ensure_image(w, floats);
         if (rc != RTX_OK) return rc;
-        uint64_t f, n;
-        split_range(count, G, g, f, n);
-        rc = render_range(w, first + (uint32_t)f, (uint32_t)n, w->d_image, w->stream, accumulate);
+        rc = render_range(w, first, count, w->d_image, w->stream, accumulate);
         if (rc != RTX_OK) return rc;
         HIP_TRY(hipEventRecord(w->ev_done, w->stream));
     }
@@ -1216,6 +1238,18 @@ int rtx_accumulate_samples(rtx_ctx *c, uint32_t sample_first, uint32_t sample_co
     return render_range(c, sample_first, sample_count, d_sum, hip_stream, true);
 }
 
+int rtx_set_share(rtx_ctx *c, uint32_t share_index, uint32_t share_count)
+{
+    if (!c) return fail(RTX_ERR_INVALID_ARG, "ctx is null");
+    if (share_count == 0u || share_index >= share_count)
+        return fail(RTX_ERR_INVALID_ARG, "rtx_set_share: share %u of %u", share_index, share_count);
+    if (is_multi(c)) return fail(RTX_ERR_UNSUPPORTED, "rtx_set_share: a multi-GPU context deals the frame out to its own GPUs");
+    c->share_index = share_index;
+    c->share_count = share_count;
+    c->progress_active = false;   // a progressive render's sums belong to the share they were started with
+    return RTX_OK;
+}
+
 int rtx_render_samples_static(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float *d_sum, void *hip_stream)
 {
     return render_range(c, sample_first, sample_count, d_sum, hip_stream, false, true);
@@ -1353,13 +1387,32 @@ int rtx_progress_begin(rtx_ctx *c, const rtx_scene *s, const float *sum, uint32_
     if (rc != RTX_OK) return rc;
     return guarded("rtx_progress_begin", [&]() -> int {
         const size_t floats = (size_t)s->width * s->height * 3u;
-        // a saved sum continues on the first GPU; the others start their shares from zero
-        for (rtx_ctx *w : workers_of(c)) {
+        // A saved sum continues, pixel by pixel, on the GPU that owns the pixel: every worker gets the sums of
+        // its own share of the frame and zeros elsewhere.  (Added up again they give the saved sum back, but for
+        // the sign of a saved -0.)
+        std::vector<rtx_ctx *> ws = workers_of(c);
+        std::vector<float> part;
+        for (rtx_ctx *w : ws) {
             DeviceGuard g(w->device);
             rc = ensure_image(w, floats);
             if (rc != RTX_OK) return rc;
-            if (sum && w == c) HIP_TRY(hipMemcpy(w->d_image, sum, floats * sizeof(float), hipMemcpyHostToDevice));
-            else HIP_TRY(hipMemset(w->d_image, 0, floats * sizeof(float)));
+            if (sum && ws.size() == 1) {
+                HIP_TRY(hipMemcpy(w->d_image, sum, floats * sizeof(float), hipMemcpyHostToDevice));
+            } else if (sum) {
+                const rtx::UnitShape shape = unit_shape_of(w);
+                part.assign(floats, 0.0f);
+                for (uint32_t y = 0; y < s->height; ++y)
+                    for (uint32_t x = 0; x < s->width; ++x) {
+                        if (rtx::unit_of_pixel(shape, s->width, x, y) % w->share_count != w->share_index) continue;
+                        const size_t at = 3u * ((size_t)y * s->width + x);
+                        part[at] = sum[at];
+                        part[at + 1] = sum[at + 1];
+                        part[at + 2] = sum[at + 2];
+                    }
+                HIP_TRY(hipMemcpy(w->d_image, part.data(), floats * sizeof(float), hipMemcpyHostToDevice));
+            } else {
+                HIP_TRY(hipMemset(w->d_image, 0, floats * sizeof(float)));
+            }
             HIP_TRY(hipDeviceSynchronize());
         }
         c->progress_done = samples_done;

@@ -98,6 +98,13 @@ struct RenderParams {
     uint32_t *queue;
     uint32_t n_chunks;
     uint32_t n_whole;
+    // The launch's share of the frame.  Work units (8x8 tiles, 16x8 blocks of the two-pixel kernel, a wavefront
+    // workgroup's tiles) are dealt out round-robin to the GPUs of a job: this launch runs units share_index,
+    // share_index + share_count, ... and touches no other pixel.  A pixel's samples are all traced and added on
+    // one GPU, in order, so the frame put together from the shares has the bits of a one-GPU frame.
+    // n_units = how many units that is (set by the launchers); tile_order, when given, lists them first.
+    uint32_t share_index, share_count;
+    uint32_t n_units;
     uint32_t ellipsoids_pow2;      // 1: every ellipsoid's radii are powers of two (kGeomPow2)
     uint32_t paths_end_at_lights;  // 1: a small all-diffuse scene whose lights are black (set at upload; picks the two-pixel scan kernel)
     uint32_t pool_entries;  // megakernel: float4 entries of a wave's hand-over pool in LDS (set by the launcher)
@@ -111,6 +118,12 @@ struct PrimaryParams {
     uint8_t *inside;
 };
 
+// units share `index` of `count` takes out of n_units dealt round-robin
+__host__ __device__ inline uint32_t share_units(uint32_t n_units, uint32_t index, uint32_t count)
+{
+    return n_units > index ? (n_units - index + count - 1u) / count : 0u;
+}
+
 // launchers implemented in the .hip files
 enum : int { kSrcLds = 0, kSrcScalar = 1, kSrcBvh = 2 };
 // scenes with more than kFewLights lights run the kernels built with the candidate-mask light pdf
@@ -121,6 +134,18 @@ hipError_t launch_megakernel(const RenderParams &p, int src, bool stats, uint32_
 uint32_t megakernel_units(const RenderParams &p, int src);
 // whether the megakernel chosen for (p, src) is the two-pixel scan kernel
 bool megakernel_two_pixels(const RenderParams &p, int src);
+// The unit a pixel belongs to under the kernel chosen for (p, src, wavefront or not): what decides which share
+// of a multi-GPU job owns the pixel.  8x8 tiles in row-major order, `tiles` consecutive ones per unit, or
+// (pair) blocks of 16x8 pixels in row-major order.
+struct UnitShape {
+    uint32_t pair, tiles;
+};
+UnitShape megakernel_unit_shape(const RenderParams &p, int src);
+inline uint32_t unit_of_pixel(UnitShape s, uint32_t width, uint32_t x, uint32_t y)
+{
+    if (s.pair) return (y >> 3) * ((width + 15u) >> 4) + (x >> 4);
+    return ((y >> 3) * ((width + 7u) >> 3) + (x >> 3)) / s.tiles;
+}
 // order[0..n_tiles) = the tiles by decreasing cost[] (buckets of one unit, costs above
 // kTileCostMax share the first bucket)
 constexpr uint32_t kTileCostMax = 2047u;

@@ -175,10 +175,15 @@ constexpr uint32_t kNoEntry = 0x3ffu;   // end of a list; pool entries are numbe
 // others are cut into chunks of the sample range, and their tickets go chunk by chunk -- all those units'
 // first chunks before all second ones -- a unit's chunks continuing its pixels' sums one after the other,
 // so a chunk waits for the one before it.  Returns false for a wave beyond the last item.
-RTX_DEV bool queue_take_item(const RenderParams &P, uint32_t slot, uint32_t n_units, uint32_t &unit, uint32_t &chunk,
+// the i-th unit of the launch: by the order table, else the i-th of this share's units (RenderParams)
+RTX_DEV uint32_t launch_unit(const RenderParams &P, uint32_t i)
+{
+    return P.tile_order ? P.tile_order[i] : P.share_index + i * P.share_count;
+}
+RTX_DEV bool queue_take_item(const RenderParams &P, uint32_t slot, uint32_t &unit, uint32_t &chunk,
                              uint32_t &sample_first, uint32_t &sample_count, bool &accumulate)
 {
-    const uint32_t n_tail = n_units - P.n_whole;
+    const uint32_t n_tail = P.n_units - P.n_whole;
     if (slot >= P.n_whole + n_tail * P.n_chunks) return false;
     uint32_t ticket = 0;
     if ((threadIdx.x & 63u) == 0u) ticket = atomicAdd(P.queue, 1u);
@@ -186,15 +191,13 @@ RTX_DEV bool queue_take_item(const RenderParams &P, uint32_t slot, uint32_t n_un
     if (ticket < P.n_whole) {
         // the first units of the order are items of their own, all samples
         chunk = 0;
-        unit = ticket;
-        if (P.tile_order) unit = P.tile_order[unit];
+        unit = launch_unit(P, ticket);
         sample_first = P.sample_first;
         sample_count = P.sample_count;
         return true;
     }
     chunk = (ticket - P.n_whole) / n_tail;
-    unit = P.n_whole + (ticket - P.n_whole) - chunk * n_tail;
-    if (P.tile_order) unit = P.tile_order[unit];
+    unit = launch_unit(P, P.n_whole + (ticket - P.n_whole) - chunk * n_tail);
     // chunk k of n samples: [n - (n >> k), n - (n >> (k + 1))), the last one up to n
     const uint32_t lo = P.sample_count - (P.sample_count >> chunk);
     const uint32_t hi = chunk + 1u == P.n_chunks ? P.sample_count : P.sample_count - (P.sample_count >> (chunk + 1u));
@@ -226,10 +229,10 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
     uint32_t sample_first = P.sample_first, sample_count = P.sample_count, chunk = 0;
     bool accumulate = P.accumulate != 0u;
     if constexpr (QUEUE) {
-        if (!queue_take_item(P, tile, tiles_x * ((P.height + 7u) >> 3), tile, chunk, sample_first, sample_count, accumulate)) return;
+        if (!queue_take_item(P, tile, tile, chunk, sample_first, sample_count, accumulate)) return;
     } else {
-        if (tile >= tiles_x * ((P.height + 7u) >> 3)) return;   // the whole wave
-        if (P.tile_order) tile = P.tile_order[tile];
+        if (tile >= P.n_units) return;   // the whole wave
+        tile = launch_unit(P, tile);
     }
     const uint32_t tile_x = (tile % tiles_x) * 8u, tile_y = (tile / tiles_x) * 8u;
     const bool in_image = tile_x + (threadIdx.x & 7u) < P.width && tile_y + ((threadIdx.x & 63u) >> 3) < P.height;
@@ -587,7 +590,6 @@ __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_
     const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
     uint32_t dbg[M_COUNT] = {};
     (void)dbg;
-    const uint32_t n_units = scan_units(P.width, P.height);
     // The wave's work item.  Without a queue: the unit of its launch slot, all samples.  With a queue
     // (P.queue, see RenderParams) the launch has one wave per (chunk of the sample range, unit) and every
     // wave draws a ticket: tickets go chunk by chunk -- all units' first chunks before all second ones --
@@ -596,11 +598,10 @@ __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_
     uint32_t unit, sample_first, sample_count, chunk = 0;
     bool accumulate = P.accumulate != 0u;
     if constexpr (QUEUE) {
-        if (!queue_take_item(P, slot, n_units, unit, chunk, sample_first, sample_count, accumulate)) return;   // the whole wave
+        if (!queue_take_item(P, slot, unit, chunk, sample_first, sample_count, accumulate)) return;   // the whole wave
     } else {
-        unit = slot;
-        if (unit >= n_units) return;   // the whole wave
-        if (P.tile_order) unit = P.tile_order[unit];
+        if (slot >= P.n_units) return;   // the whole wave
+        unit = launch_unit(P, slot);
         sample_first = P.sample_first;
         sample_count = P.sample_count;
     }
@@ -968,6 +969,10 @@ uint32_t megakernel_units(const RenderParams &p, int src)
 }
 
 bool megakernel_two_pixels(const RenderParams &p, int src) { return two_pixels_per_lane(p, src); }
+UnitShape megakernel_unit_shape(const RenderParams &p, int src)
+{
+    return two_pixels_per_lane(p, src) ? UnitShape{1u, 1u} : UnitShape{0u, 1u};
+}
 
 hipError_t launch_megakernel(const RenderParams &p0, int src, bool stats, uint32_t pool_limit, hipStream_t stream)
 {
@@ -975,8 +980,11 @@ hipError_t launch_megakernel(const RenderParams &p0, int src, bool stats, uint32
     const bool two = two_pixels_per_lane(p, src);
     if (stats) p.queue = nullptr;
     const uint32_t waves = two ? kScan2Block / 64u : 4u;   // per workgroup
+    p.n_units = share_units(megakernel_units(p, src), p.share_index, p.share_count);
+    if (p.n_units == 0u) return hipSuccess;   // more shares than units: nothing of the frame is this one's
+    if (p.queue && p.n_whole > p.n_units) p.n_whole = p.n_units;
     // a wave per work item
-    const uint32_t slots = p.queue ? p.n_whole + (megakernel_units(p, src) - p.n_whole) * p.n_chunks : megakernel_units(p, src);
+    const uint32_t slots = p.queue ? p.n_whole + (p.n_units - p.n_whole) * p.n_chunks : p.n_units;
     const dim3 grid((slots + waves - 1u) / waves);
     // sixteen waves share a CU's 160 KB of LDS: what the table (scan) or the traversal
     // stacks (BVH), and the parked pixel contexts of the two-pixel kernel, leave of a workgroup's

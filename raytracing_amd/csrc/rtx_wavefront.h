@@ -22,5 +22,7 @@ size_t wavefront_state_bytes(uint32_t width, uint32_t height);
 void wavefront_bind_state(void *block, uint32_t width, uint32_t height, WfState &S);
 // Renders samples [P.sample_first, +P.sample_count) into P.out_sum: one asynchronous launch.
 hipError_t launch_wavefront(const RenderParams &P, const WfState &S, int src, bool stats, hipStream_t stream);
+// 8x8 tiles (consecutive in row-major order) a workgroup of the variant chosen for (P, src) owns: its work unit
+uint32_t wavefront_group_tiles(const RenderParams &P, int src);
 
 }  // namespace rtx

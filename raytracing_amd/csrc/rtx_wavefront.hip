@@ -118,7 +118,8 @@ RTX_DEV void wf_push(WfLds<PIXELS> &L, int q, bool pred, uint32_t value, uint32_
 template <uint32_t TILES>
 RTX_DEV bool wf_pixel(const RenderParams &P, uint32_t local, uint32_t &px, uint32_t &py)
 {
-    const uint32_t tile = blockIdx.x * TILES + (local >> 6);
+    // the workgroup's unit: units are dealt out round-robin to the shares of a multi-GPU job
+    const uint32_t tile = (P.share_index + blockIdx.x * P.share_count) * TILES + (local >> 6);
     const uint32_t in_tile = local & 63u;
     const uint32_t tiles_x = (P.width + 7u) >> 3;
     px = (tile % tiles_x) * 8u + (in_tile & 7u);
@@ -656,7 +657,9 @@ template <int SRC, bool STATS, bool MANY_LIGHTS, class SHAPE>
 static hipError_t launch_variant(const RenderParams &P, const WfState &S, hipStream_t stream)
 {
     const uint32_t tiles = ((P.width + 7u) / 8u) * ((P.height + 7u) / 8u);
-    const dim3 grid((tiles + SHAPE::kTiles - 1u) / SHAPE::kTiles);
+    const uint32_t groups = share_units((tiles + SHAPE::kTiles - 1u) / SHAPE::kTiles, P.share_index, P.share_count);
+    if (groups == 0u) return hipSuccess;
+    const dim3 grid(groups);
     const size_t lds = wavefront_lds_bytes<SHAPE>(P, SRC);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wavefront<SRC, STATS, MANY_LIGHTS, SHAPE>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -674,6 +677,12 @@ template <int SRC, class SHAPE>
 static hipError_t launch_src(const RenderParams &P, const WfState &S, bool stats, hipStream_t stream)
 {
     return stats ? launch_one<SRC, true, SHAPE>(P, S, stream) : launch_one<SRC, false, SHAPE>(P, S, stream);
+}
+
+uint32_t wavefront_group_tiles(const RenderParams &P, int src)
+{
+    if (src == kSrcBvh) return wavefront_state_in_lds(P, kSrcBvh) ? ShapeBvhLds::kTiles : ShapeBvhHbm::kTiles;
+    return ShapeScan::kTiles;
 }
 
 hipError_t launch_wavefront(const RenderParams &P, const WfState &S, int src, bool stats, hipStream_t stream)

@@ -31,6 +31,7 @@ SYMBOLS = {
     "rtx_render_samples": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rtx_render_samples_static": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
     "rtx_accumulate_samples": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]),
+    "rtx_set_share": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "rtx_tonemap_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_float, C.c_void_p, C.c_void_p]),
     "rtx_render_bytes": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene), C.POINTER(C.c_uint8)]),
     "rtx_progress_begin": (C.c_int, [C.c_void_p, C.POINTER(_abi.rtx_scene), _FP, C.c_uint32]),
@@ -189,6 +190,12 @@ class Renderer:
         """Sum of samples [first, first+count) into a device buffer (raw pointer)."""
         _check(self._lib.rtx_render_samples(self._ctx, sample_first, sample_count,
                                             C.c_void_p(d_sum_ptr), C.c_void_p(stream)))
+
+    def set_share(self, share_index: int, share_count: int):
+        """One process per GPU: from now on render_samples covers share `share_index` of `share_count` of the
+        frame's work units and writes zeros elsewhere; the shares' buffers added up are the one-GPU frame, bit
+        for bit."""
+        _check(self._lib.rtx_set_share(self._ctx, share_index, share_count))
 
     def render_samples_static(self, sample_first: int, sample_count: int, d_sum_ptr: int, stream: int = 0):
         """render_samples without any device allocation (static tile tables)."""

@@ -1,8 +1,9 @@
-"""The multi-GPU path (samples split over ranks, all-reduce of the radiance sums, divide)
-exercised with world_size 2 and 3 over gloo on the CPU.  The renderer is replaced by a
-test double that fills the rank's buffer with the ORACLE's partial sums, so what is
+"""The process-per-GPU path (the frame's work units dealt out to the ranks, all-reduce of the radiance sums,
+divide) exercised with world_size 2 and 3 over gloo on the CPU.  The renderer is replaced by a
+test double that fills the rank's buffer with the ORACLE's sums of the rank's share of the frame (blocks of
+16 x 8 pixels dealt out round-robin, zeros elsewhere -- what rtx_set_share makes the kernels write), so what is
 tested here is the partition, the collective and the final division -- the same
-`render_distributed` code the GPU ranks run."""
+`render_distributed` code the GPU ranks run -- and that the result has the bits of a one-rank render."""
 import os
 import socket
 import sys
@@ -38,7 +39,11 @@ class OracleDouble:
     """Stands in for raytracing_amd.renderer.Renderer on a machine without a GPU."""
 
     def __init__(self, seed, buf):
-        self.seed, self.buf, self.scene = seed, buf, None
+        self.seed, self.buf, self.scene, self.share = seed, buf, None, (0, 1)
+
+    def set_share(self, index, count):
+        assert 0 <= index < count
+        self.share = (index, count)
 
     def set_scene(self, scene):
         self.scene = scene
@@ -48,6 +53,11 @@ class OracleDouble:
         assert ptr == self.buf.data_ptr()
         part = pyoracle.render(self.scene, seed=self.seed, order=pyoracle.ORDER_FORWARD,
                                sample_first=first, sample_count=count, output_sum=True)
+        # the share's pixels: units of 16 x 8 pixels in row-major order, dealt out round-robin
+        h, w = part.shape[:2]
+        y, x = np.mgrid[0:h, 0:w]
+        unit = (y // 8) * ((w + 15) // 16) + x // 16
+        part = np.where((unit % self.share[1] == self.share[0])[..., None], part, np.float32(0)).astype(np.float32)
         self.buf.copy_(torch.from_numpy(part.reshape(-1)))
 
     def divide(self, ptr, n, divisor, stream=0):
@@ -80,7 +90,7 @@ def _worker(rank, world, port, spp, out_path):
 
 
 @pytest.mark.parametrize("world,spp", [(2, 8), (3, 7), (2, 1), (2, 0)])
-def test_spp_split_allreduce_matches_single_rank(tmp_path, world, spp, oracle):
+def test_frame_shares_allreduce_matches_single_rank(tmp_path, world, spp, oracle):
     out = str(tmp_path / "img.npy")
     mp.spawn(_worker, args=(world, _free_port(), spp, out), nprocs=world, join=True)
     got = np.load(out)
@@ -91,7 +101,7 @@ def test_spp_split_allreduce_matches_single_rank(tmp_path, world, spp, oracle):
         return
     want_fwd = oracle.render(sc, seed=5, order=oracle.ORDER_FORWARD).reshape(-1)
     want_ref = oracle.render(sc, seed=5, order=oracle.ORDER_REFERENCE).reshape(-1)
-    # partial sums are added in a different order than a single rank adds samples
-    assert np.allclose(got, want_fwd, rtol=1e-6, atol=0)
+    # every pixel is one rank's sum plus the other ranks' zeros: the bits of a single rank
+    assert np.array_equal(got.view(np.uint32), want_fwd.view(np.uint32))
     err = np.abs(got - want_ref) / np.maximum(np.maximum(np.abs(got), np.abs(want_ref)), 1e-6)
     assert err.max() <= 1e-5
