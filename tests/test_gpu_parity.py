@@ -861,10 +861,11 @@ def test_ten_thousand_objects_equal_the_linear_scan_oracle(oracle):
         assert np.array_equal(want.view(np.uint32), got.view(np.uint32)), mode
 
 
-def test_4k_frame_through_the_sample_split(oracle):
-    """3840 x 2160, the multi-GPU configuration's frame, at 2 samples per pixel: one sample range
-    per call, as two GPUs would render them, each equal to the oracle's partial sums bit for bit;
-    then the same split inside the library (two workers on this GPU) against their sum."""
+def test_4k_frame_in_steps_and_in_shares(oracle):
+    """3840 x 2160, the multi-GPU configuration's frame, at 2 samples per pixel: one sample step per call, each
+    equal to the oracle's sums bit for bit; then the frame dealt out to two workers inside the library and to two
+    contexts with their shares set (as two processes would hold them) against the steps' sum -- two samples added
+    to zero are the same two additions in either order."""
     import torch
     sc = reference_scene(width=3840, height=2160, n_samples=2)
     threads = max(1, min(16, len(os.sched_getaffinity(0))))
@@ -883,8 +884,18 @@ def test_4k_frame_through_the_sample_split(oracle):
         assert np.array_equal(want.view(np.uint32), parts[first].view(np.uint32)), first
     with Renderer(seed=1, devices=[0, 0]) as r:
         got = r.render(sc)
-    want = ((parts[0] + parts[1]) / np.float32(2.0)).astype(np.float32)
+    total = (parts[0] + parts[1]).astype(np.float32)
+    want = (total / np.float32(2.0)).astype(np.float32)
     assert np.array_equal(want.view(np.uint32), got.view(np.uint32))
+    added = np.zeros(n, dtype=np.float32)
+    for share in (0, 1):
+        with Renderer(seed=1) as r:
+            r.set_share(share, 2)
+            r.set_scene(sc)
+            r.render_samples(0, 2, buf.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            added = (added + buf.cpu().numpy()).astype(np.float32)
+    assert np.array_equal(total.reshape(-1).view(np.uint32), added.view(np.uint32))
 
 
 def test_zero_throughput_rule_matches_full_paths_and_is_off_for_untame_scenes(oracle):

@@ -234,6 +234,7 @@ def main():
     big = int(os.environ.get("SWEEP_BIG", "1"))   # image edge and sample count multiplier
     options = os.environ.get("SWEEP_OPTIONS") == "1"
     reuse = os.environ.get("SWEEP_REUSE") == "1"
+    workers = int(os.environ.get("SWEEP_WORKERS", "1"))
     kept = {}
     same = lambda a, b: bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
     for seed in range(first, first + n):
@@ -256,6 +257,8 @@ def main():
                 if (mode, accel) not in kept:
                     kept[(mode, accel)] = Renderer(seed=1, mode=mode, accel=accel)
                 r = kept[(mode, accel)]
+            elif workers > 1:   # SWEEP_WORKERS=N: the frame dealt out to N workers on this GPU, the same image expected
+                r = Renderer(seed=seed, mode=mode, accel=accel, devices=[0] * workers)
             else:
                 r = Renderer(seed=seed, mode=mode, accel=accel)
             try:
