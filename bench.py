@@ -416,7 +416,10 @@ def main():
                                "traffic_source": prof["source"] if prof else None,
                                "per": "GPU (the kernel runs on every GPU side by side: a GPU's share of the FLOPs / the slowest GPU's kernel time)",
                                "frac_of_nonpacked_fma_peak": head["frac_of_nonpacked_fma_peak"],
-                               "kernel": ("k_megakernel (probe launch of 8 samples, k_tile_order, main launch in cost order)"
+                               "kernel": (("k_megakernel_scan2 (two pixels per lane; units drawn from a work queue, the last 8 192 in chunks of the sample range)"
+                                           if name in ("c2", "c4", "c1") else
+                                           "k_megakernel (units longest first: the scene's tile costs are measured once, by an 8-sample probe launch "
+                                           "of the first render after rtx_set_scene -- here in the warm-up -- and reused by the timed renders)")
                                           if args.mode == "megakernel" else "k_wavefront"),
                                "kernel_ms": head["kernel_ms"], "algorithmic_flops_per_launch": head["algorithmic_flops_per_launch"],
                                "algorithmic_flops_elided": head["algorithmic_flops_elided"],

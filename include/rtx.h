@@ -155,7 +155,10 @@ void rtx_destroy(rtx_ctx *ctx);
  * `Scene` from parse_scene to render (src/main.rs:37-38).
  * RTX_ERR_INVALID_SCENE where the reference would panic: width/height 0, an
  * emissive box with a half-size <= 0 (src/objects/sample.rs:30,46 gen_range on an empty
- * range). */
+ * range).
+ * The first render of 64 or more samples of a large frame after this call may spend a short extra
+ * launch on measuring what each block of the frame costs, so that this and later renders of the scene
+ * can start the expensive blocks first; that changes when a pixel is rendered, never its value. */
 int rtx_set_scene(rtx_ctx *ctx, const rtx_scene *scene);
 
 /* Drop-in for `render(&mut scene)` (src/main.rs:13-31): renders scene->n_samples

@@ -198,6 +198,10 @@ struct rtx_ctx {
     size_t d_wavefront_bytes = 0;
     uint32_t *d_tiles = nullptr;  // cost and dispatch order of the 8x8 tiles, n_tiles words each
     size_t d_tiles_words = 0;
+    // The order table of d_tiles is still the one measured for the scene, frame size and share in use: a scene is
+    // measured once (the probe launch of render_range), and later renders of it are dispatched by that order.
+    bool order_valid = false;
+    uint32_t order_units = 0;
     uint32_t *static_tiles = nullptr;   // device address of this GPU's `scratch`
     uint32_t pool_limit = rtx::kPoolEntriesMax;   // cap of the megakernel's hand-over pool (RTX_POOL_ENTRIES)
     // this context's share of every frame (rtx_set_share; the workers of a multi-GPU context: worker g of G)
@@ -829,7 +833,10 @@ int rtx_set_scene(rtx_ctx *c, const rtx_scene *s)
     if (rc != RTX_OK) return rc;
     return guarded("rtx_set_scene", [&]() -> int {
         std::vector<rtx_ctx *> ws = workers_of(c);
-        for (rtx_ctx *w : ws) w->have_scene = false;
+        for (rtx_ctx *w : ws) {
+            w->have_scene = false;
+            w->order_valid = false;   // another scene costs its tiles differently
+        }
         c->scene = *s;
         c->prims.assign(s->prims, s->prims + s->n_prims);
         c->scene.prims = nullptr;
@@ -886,7 +893,7 @@ constexpr uint32_t kProbeSamples = RTX_PROBE_SAMPLES, kOrderedMinSamples = 64u, 
 #define RTX_CHUNK_MIN 16u
 #endif
 #ifndef RTX_CHUNK_MIN_ONE
-#define RTX_CHUNK_MIN_ONE 32u
+#define RTX_CHUNK_MIN_ONE 33u   // 64 samples stay one item (10 000 objects, 64 samples: two chunks of 32 139.3 ms, one item 132.9 ms)
 #endif
 #ifndef RTX_CHUNK_MAX
 #define RTX_CHUNK_MAX 6u
@@ -901,6 +908,9 @@ constexpr uint32_t kChunkMin = RTX_CHUNK_MIN, kChunkMinOnePixel = RTX_CHUNK_MIN_
 #endif
 #ifndef RTX_QUEUE_TAIL
 #define RTX_QUEUE_TAIL 8192u
+#endif
+#ifndef RTX_REUSE_ORDER
+#define RTX_REUSE_ORDER 1   // 0: every call measures the scene again (a probe launch per call)
 #endif
 constexpr uint32_t kQueueTail = RTX_QUEUE_TAIL;   // units at the end of the order that are cut into chunks
 // the launch that follows the probe renders sample_count - kProbeSamples samples: at least one
@@ -1008,6 +1018,7 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
                     if (c->d_tiles) (void)hipFree(c->d_tiles);
                     c->d_tiles = nullptr;
                     c->d_tiles_words = 0;
+                    c->order_valid = false;
                     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&c->d_tiles), words * sizeof(uint32_t)));
                     c->d_tiles_words = words;
                 }
@@ -1023,6 +1034,14 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
         const bool two_pixel = probe != 0u && (RTX_ONE_PIXEL_PLAN == 1 || rtx::megakernel_two_pixels(P, c->src));
         if (two_pixel) probe = 0u;
         const uint32_t chunk_min = two_pixel ? kChunkMin : kChunkMinOnePixel;
+        if (probe && RTX_REUSE_ORDER && !no_alloc && c->order_valid && c->order_units == rtx::megakernel_units(P, c->src)) {
+            // The scene has been measured (an earlier call on this context, same frame size and share): its units
+            // go out in that order again, all samples in one launch -- no probe, whose launch costs every unit a
+            // wave's start and end (as much as 2.8 samples of each pixel) and has an end of its own.  The order
+            // only decides which wave starts when, so a cost table that is a call old changes no bit.
+            probe = 0u;
+            P.tile_order = tiles + n_tiles;
+        }
         if (probe) {
             // the launch deals out work units (8 x 8 tiles or pairs of them): at most n_tiles
             const uint32_t n_units = rtx::megakernel_units(P, c->src);
@@ -1038,6 +1057,10 @@ int render_range(rtx_ctx *c, uint32_t sample_first, uint32_t sample_count, float
             P.sample_count = sample_count - probe;
             P.accumulate = 1u;
             P.tile_order = order;
+            if (!no_alloc) {
+                c->order_valid = true;
+                c->order_units = n_units;
+            }
         }
         if (tiles) {
             // the samples in chunks -- halves of what is left, down to chunk_min samples -- drawn from a
@@ -1246,6 +1269,7 @@ int rtx_set_share(rtx_ctx *c, uint32_t share_index, uint32_t share_count)
     if (is_multi(c)) return fail(RTX_ERR_UNSUPPORTED, "rtx_set_share: a multi-GPU context deals the frame out to its own GPUs");
     c->share_index = share_index;
     c->share_count = share_count;
+    c->order_valid = false;
     c->progress_active = false;   // a progressive render's sums belong to the share they were started with
     return RTX_OK;
 }

@@ -697,6 +697,53 @@ def test_work_queue_of_sample_chunks_changes_no_bits(which):
     assert np.array_equal(continued.view(np.uint32), plain.view(np.uint32))
 
 
+@pytest.mark.parametrize("which", ["one_pixel_scan", "bvh", "bvh_many_lights"])
+def test_a_scene_is_measured_once_and_its_order_reused_without_changing_a_bit(which):
+    """The first render of enough samples of a scene measures what each tile costs (a probe launch) and dispatches
+    the rest longest first; later renders on the context skip the probe and go out in that order, until the scene
+    is set again.  Three steps of a progressive render (the second measures, the third reuses, with and without the
+    work queue), then two whole renders through rtx_render_samples (measure, reuse) and one after the share was
+    changed and changed back (measured again): the bits of a counting context's single plain launch."""
+    import dataclasses
+    import torch
+    from raytracing_amd import synthetic_scene
+    sc = reference_scene(width=1021, height=771, n_samples=214)
+    if which == "one_pixel_scan":
+        prims = list(sc.prims)
+        prims[5] = dataclasses.replace(prims[5], color=(0.7, 0.7, 0.7))
+        sc = sc.replace(prims=prims)
+    elif which == "bvh":
+        sc = dielectric_scene(width=1021, height=771, n_samples=214, ray_depth=8)
+    else:
+        sc = synthetic_scene(n_prims=300, seed=5, width=1021, height=771, n_samples=214, ray_depth=4)
+    n = sc.width * sc.height * 3
+    with Renderer(seed=21) as r:
+        r.progress_begin(sc)
+        r.progress_step(10)
+        r.progress_step(70)      # measures
+        r.progress_step(70)      # reuses, one launch
+        r.progress_step(64)      # reuses
+        steps, done = r.progress_read("sum")
+        assert done == 214
+        buf = torch.empty(n, dtype=torch.float32, device="cuda")
+        whole = []
+        for k in range(3):
+            if k == 2:
+                r.set_share(0, 2)
+                r.set_share(0, 1)
+            r.render_samples(0, 214, buf.data_ptr())
+            torch.cuda.synchronize()
+            whole.append(buf.cpu().numpy().reshape(steps.shape))
+    with Renderer(seed=21, collect_stats=True) as r:
+        r.progress_begin(sc)
+        r.progress_step(214)
+        plain, _ = r.progress_read("sum")
+    assert np.isfinite(plain).all() and plain.mean() > 0.5
+    assert np.array_equal(steps.view(np.uint32), plain.view(np.uint32))
+    for k in range(3):
+        assert np.array_equal(whole[k].view(np.uint32), plain.view(np.uint32)), k
+
+
 def test_device_tonemap_matches_the_host_output_stage():
     from raytracing_amd import host
     sc = reference_scene(width=160, height=120, n_samples=6)
