@@ -382,28 +382,27 @@ RTX_DEV void scan_axis_plane_pair(const Table &tab, uint32_t begin, V3 o, V3 d, 
     }
 }
 
-template <int CAT>
+// PAIRS: bit k set = axis category k holds exactly two planes (two walls of a room that face each other), tested
+// as a pair.  The choice is made once for the whole scan (scan_by_category) among three compiled forms -- no pairs,
+// x and y, all three axes -- so the categories that follow are compiled three times: a choice at every axis, each
+// followed by its own copy of the rest, made eight copies (100 KB of code per kernel), and one merged copy behind a
+// choice per axis measured 0.5 % slower on the reference scene.
+template <int CAT, int PAIRS>
 RTX_DEV void scan_categories_from(const Table &tab, const uint32_t (&ends)[kScanHeader], uint32_t begin, V3 o, V3 d,
                                   float ray_length, int &best, float &best_t)
 {
     if constexpr (CAT < kScanCats) {
-#if RTX_PLANE_PAIRS
-        if constexpr (CAT == kCatPlaneX || CAT == kCatPlaneY || CAT == kCatPlaneZ) {
-            if (ends[CAT] - begin == 2u) {
-                scan_axis_plane_pair<CAT>(tab, begin, o, d, ray_length, best, best_t);
-                scan_categories_from<CAT + 1>(tab, ends, ends[CAT], o, d, ray_length, best, best_t);
-                return;
-            }
-        }
-#endif
-        scan_category<CAT>(tab, begin, ends[CAT], o, d, ray_length, best, best_t);
+        if constexpr (CAT <= kCatPlaneZ && ((PAIRS >> CAT) & 1) != 0)
+            scan_axis_plane_pair<CAT>(tab, begin, o, d, ray_length, best, best_t);
+        else
+            scan_category<CAT>(tab, begin, ends[CAT], o, d, ray_length, best, best_t);
 #ifdef RTX_X_REPEAT_CATS   // timing experiment: the categories of this bit mask run twice
         if constexpr (((RTX_X_REPEAT_CATS) >> CAT) & 1) {
             asm volatile("" : "+v"(o.x), "+v"(d.x));
             scan_category<CAT>(tab, begin, ends[CAT], o, d, ray_length, best, best_t);
         }
 #endif
-        scan_categories_from<CAT + 1>(tab, ends, ends[CAT], o, d, ray_length, best, best_t);
+        scan_categories_from<CAT + 1, PAIRS>(tab, ends, ends[CAT], o, d, ray_length, best, best_t);
     }
 }
 RTX_DEV void scan_by_category(const Table &tab, V3 o, V3 d, float ray_length, int &best, float &best_t)
@@ -419,7 +418,11 @@ RTX_DEV void scan_by_category(const Table &tab, V3 o, V3 d, float ray_length, in
         ends[4 * q + 2] = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z);
         ends[4 * q + 3] = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w);
     }
-    scan_categories_from<0>(tab, ends, 0u, o, d, ray_length, best, best_t);
+    static_assert(kCatPlaneX == 0 && kCatPlaneY == 1 && kCatPlaneZ == 2, "the axis categories come first");
+    const bool xy = RTX_PLANE_PAIRS && ends[kCatPlaneX] == 2u && ends[kCatPlaneY] == 4u;
+    if (xy && ends[kCatPlaneZ] == 6u) scan_categories_from<0, 7>(tab, ends, 0u, o, d, ray_length, best, best_t);
+    else if (xy) scan_categories_from<0, 3>(tab, ends, 0u, o, d, ray_length, best, best_t);
+    else scan_categories_from<0, 0>(tab, ends, 0u, o, d, ray_length, best, best_t);
 }
 
 // Closest hit over the whole table, linear scan in object order.  The first object
