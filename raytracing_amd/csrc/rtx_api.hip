@@ -554,6 +554,13 @@ void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
     // twice as many lanes as still descend, trees of a few hundred objects and more when they do not wait
     // (60 objects: 90.3 against 92.1 ms; 200: 101.1 / 100.4; 10 000: 156.8 / 151.6; 40 000: 152.4 / 144.1)
     P.bvh.leaf_cost = P.bvh.n_nodes >= 128u ? 1u : 2u;
+    // The smaller the tree, the more a wave gains from going on until few lanes traverse: its traversals are short
+    // and its surface interactions, which then run fuller, are most of the work.  Measured (ms per frame for 1 - 6
+    // sixteenths): glass scene, 27 nodes, 191.6 189.4 191.6 198.1 201.5 209.2; 300 objects - 90.9 91.9 94.6; 1 000 objects
+    // 106.8 104.7 104.6 106.7 110.1 113.9; 3 000 - 127.5 128.4 126.6; 10 000 147.0 139.0 135.1 133.1 132.7 133.1;
+    // 20 000 - 132.5 126.5 126.1; 100 000 165.3 160.6 161.4 160.6 163.5 160.8.
+    P.bvh.exit_sixteenths = P.bvh.n_nodes < 2048u ? 2u : 4u;
+    if (const char *e = std::getenv("RTX_EXIT_SIXTEENTHS")) P.bvh.exit_sixteenths = (uint32_t)std::min(16l, std::max(1l, std::strtol(e, nullptr, 10)));
 }
 
 // one worker's copy of the block; the worker's device must be current

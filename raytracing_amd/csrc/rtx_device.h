@@ -57,6 +57,8 @@ struct BvhView {
     uint32_t n_nodes, n_planes;
     uint32_t stack_entries;   // postponed nodes a traversal can hold: the tree's depth + 1
     uint32_t leaf_cost;         // megakernel: lanes at a leaf wait until they outnumber the descending ones this many times
+    uint32_t exit_sixteenths;   // megakernel: the wave leaves its traversal loop when fewer than this many sixteenths of its
+                                // active lanes still traverse (the others go on to their surface interaction)
 };
 
 // kernel parameters: passed by value, so every field sits in scalar registers

@@ -109,15 +109,9 @@ RTX_DEV int closest_hit(const RenderParams &P, const Table &tab, V3 o, V3 d, flo
     else return closest_hit_scan<true>(tab, o, d, t);
 }
 
-// BVH scenes: the wave leaves its traversal loop when fewer than NUM / DEN of its active lanes are
-// still traversing; an object test is worth LEAF_COST node steps (default: BvhView::leaf_cost,
-// chosen by the size of the tree); node steps come in batches.
-#ifndef RTX_MK_TRAV_NUM
-#define RTX_MK_TRAV_NUM 1u
-#endif
-#ifndef RTX_MK_TRAV_DEN
-#define RTX_MK_TRAV_DEN 4u
-#endif
+// BVH scenes: the wave leaves its traversal loop when fewer than BvhView::exit_sixteenths / 16 of its active
+// lanes are still traversing; an object test is worth LEAF_COST node steps (default: BvhView::leaf_cost); both
+// are chosen by the size of the tree at upload; node steps come in batches.
 #ifndef RTX_MK_LEAF_COST
 #define RTX_MK_LEAF_COST P.bvh.leaf_cost
 #endif
@@ -384,7 +378,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
 #endif
             const BvhRay R = bvh_ray_setup(P.bvh, p.o, p.d);
             const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
-            const uint32_t threshold = max(1u, n_active * RTX_MK_TRAV_NUM / RTX_MK_TRAV_DEN);
+            const uint32_t threshold = max(1u, n_active * P.bvh.exit_sixteenths >> 4);
             for (;;) {
                 const bool at_leaf = cur < 0 && cur != kBvhEmpty;
                 const uint32_t n_node = (uint32_t)__popcll(__ballot(cur >= 0));
