@@ -560,6 +560,10 @@ void build_scene_block(const rtx_ctx *c, SceneBlock &blk)
     // 106.8 104.7 104.6 106.7 110.1 113.9; 3 000 - 127.5 128.4 126.6; 10 000 147.0 139.0 135.1 133.1 132.7 133.1;
     // 20 000 - 132.5 126.5 126.1; 100 000 165.3 160.6 161.4 160.6 163.5 160.8.
     P.bvh.exit_sixteenths = P.bvh.n_nodes < 2048u ? 2u : 4u;
+    // tuning aids (like RTX_POOL_ENTRIES): either weight from the environment.  Object-test weights of 1 - 4 with the
+    // thresholds above: glass scene 192.5 / 189.7 / 189.2 / 189.0 ms, 60 objects 78.4 / 78.5 / 78.9 / 79.2, 1 000
+    // objects 105.0 / 107.7 / 110.3 / 112.7, 10 000 objects 134.1 / 138.7 / 142.4 / 146.8 -- the rule above stands.
+    if (const char *e = std::getenv("RTX_LEAF_COST")) P.bvh.leaf_cost = (uint32_t)std::min(64l, std::max(1l, std::strtol(e, nullptr, 10)));
     if (const char *e = std::getenv("RTX_EXIT_SIXTEENTHS")) P.bvh.exit_sixteenths = (uint32_t)std::min(16l, std::max(1l, std::strtol(e, nullptr, 10)));
 }
 
