@@ -110,17 +110,45 @@ constexpr float kBvhMaxMargin = 16384.0f;
 // object tests can report a hit for origins inside the grid; the zone grows by at most
 // far_slope per world unit the origin lies outside it (rtx_bvh.cpp: world_bounds), and the
 // f32 value of the origin in grid units is off by up to 2^-23 of its magnitude.
-RTX_DEV BvhRay bvh_ray_setup(const BvhView &B, V3 o, V3 d)
+// The grid of the node boxes as the ray set-up reads it: from the kernel's arguments, or from the kernel's LDS copy
+// of them (Table::uniforms, floats 24-34: base, -, inverse step, far slope, step) so that ten scalar registers are
+// not held through the traversal loop for something read once per round.
+struct BvhGrid {
+    V3 base, inv_step, step;
+    float far_slope;
+};
+RTX_DEV BvhGrid bvh_grid(const BvhView &B)
+{
+    BvhGrid G;
+    G.base = v3(B.grid_base[0], B.grid_base[1], B.grid_base[2]);
+    G.inv_step = v3(B.grid_inv_step[0], B.grid_inv_step[1], B.grid_inv_step[2]);
+    G.step = v3(B.grid_step[0], B.grid_step[1], B.grid_step[2]);
+    G.far_slope = B.far_slope;
+    return G;
+}
+RTX_DEV BvhGrid bvh_grid(const BvhView &B, const Table &tab)
+{
+    if (!tab.has_uniforms) return bvh_grid(B);
+    const float4 a = *reinterpret_cast<const float4 *>(tab.uniforms + 24), b = *reinterpret_cast<const float4 *>(tab.uniforms + 28),
+                 c = *reinterpret_cast<const float4 *>(tab.uniforms + 32);
+    BvhGrid G;
+    G.base = v3(a.x, a.y, a.z);
+    G.inv_step = v3(b.x, b.y, b.z);
+    G.far_slope = b.w;
+    G.step = v3(c.x, c.y, c.z);
+    return G;
+}
+RTX_DEV BvhRay bvh_ray_setup(const BvhGrid &B, V3 o, V3 d)
 {
     BvhRay R;
-    const V3 gs = v3(B.grid_inv_step[0], B.grid_inv_step[1], B.grid_inv_step[2]);
-    const V3 og = cmul(o - v3(B.grid_base[0], B.grid_base[1], B.grid_base[2]), gs);
+    const V3 gs = B.inv_step;
+    const V3 og = cmul(o - B.base, gs);
     const V3 dg = cmul(d, gs);
     R.inv = cdiv(v3(1.0f, 1.0f, 1.0f), dg);
     const float gmax = (float)kBvhGridMax;
     const V3 outside = v3(fmaxf(fmaxf(-og.x, og.x - gmax), 0.0f), fmaxf(fmaxf(-og.y, og.y - gmax), 0.0f),
                           fmaxf(fmaxf(-og.z, og.z - gmax), 0.0f));                      // grid units
-    const float outside_world = (outside.x * B.grid_step[0] + outside.y * B.grid_step[1]) + outside.z * B.grid_step[2];
+    const float outside_world = (outside.x * B.step.x + outside.y * B.step.y) + outside.z * B.step.z;
     const float grow = B.far_slope * outside_world * 1.01f;                             // world units
     const V3 margin = v3(grow * gs.x + 4e-7f * (fabsf(og.x) + gmax), grow * gs.y + 4e-7f * (fabsf(og.y) + gmax),
                          grow * gs.z + 4e-7f * (fabsf(og.z) + gmax));                   // grid units
@@ -204,7 +232,7 @@ RTX_DEV int closest_hit_bvh(const BvhView &B, const Table &tab, V3 o, V3 d, floa
     if (B.n_nodes == 0) return best;
     const bool leaves_plain = all_plain;   // wave-uniform
 
-    const BvhRay R = bvh_ray_setup(B, o, d);
+    const BvhRay R = bvh_ray_setup(bvh_grid(B, tab), o, d);
     int sp = 0;
     int32_t cur = 0;  // >= 0 inner node, < 0 leaf of object ~cur, kBvhEmpty = finished
     for (;;) {

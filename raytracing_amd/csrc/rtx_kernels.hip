@@ -23,9 +23,21 @@ namespace rtx {
 
 extern __shared__ float4 rtx_smem[];
 
-__host__ __device__ inline uint32_t table_lds_bytes(uint32_t n_prims, uint32_t n_lights)
+// What a kernel of this file needs now and then but not in its inner loops -- the camera (once per sample), the
+// background colour (a ray that leaves the scene), the constant draw words of RTX_RNG_CONST -- is copied to LDS at
+// the start: as kernel arguments these numbers sit in scalar registers through the whole loop, where the compiler
+// spills and reloads them around every surface interaction (reference scene at 4K: 893 -> 869 ms with the camera
+// alone moved).  Layout in floats: camera position 0-2, axes 4-12, tangents 13-14, background 16-18, draw words 20-23,
+// and the grid of the BVH's node boxes (rtx_bvh_traverse.hpp: bvh_grid): base 24-26, inverse step 28-30, far slope
+// 31, step 32-34.
+constexpr uint32_t kUniformFloats = 36u;
+__host__ __device__ inline uint32_t table_only_lds_bytes(uint32_t n_prims, uint32_t n_lights)
 {
     return (n_prims * 6u * (uint32_t)sizeof(float4) + (n_lights + kScanHeader + n_prims + 2u) * (uint32_t)sizeof(int32_t) + 15u) & ~15u;
+}
+__host__ __device__ inline uint32_t table_lds_bytes(uint32_t n_prims, uint32_t n_lights)
+{
+    return table_only_lds_bytes(n_prims, n_lights) + kUniformFloats * (uint32_t)sizeof(float);
 }
 size_t scene_lds_bytes(uint32_t n_prims, uint32_t n_lights) { return table_lds_bytes(n_prims, n_lights); }
 // dynamic LDS every kernel of this file starts with: the object table or the traversal stacks
@@ -33,12 +45,31 @@ template <int SRC>
 __host__ __device__ inline uint32_t fixed_lds_bytes(const RenderParams &P)
 {
     if (SRC == kSrcLds) return table_lds_bytes(P.n_prims, P.n_lights);
-    if (SRC == kSrcBvh) return P.bvh.stack_entries * 256u * (uint32_t)sizeof(int32_t);
-    return 0u;
+    if (SRC == kSrcBvh) return P.bvh.stack_entries * 256u * (uint32_t)sizeof(int32_t) + kUniformFloats * (uint32_t)sizeof(float);
+    return kUniformFloats * (uint32_t)sizeof(float);
+}
+// every thread of the workgroup calls it; the caller synchronises before the first read
+RTX_DEV void stage_uniforms(const RenderParams &P, float *u)
+{
+    const uint32_t k = threadIdx.x;
+    if (k < kUniformFloats) {
+        float v = 0.0f;
+        if (k < 3u) v = P.cam_pos[k];
+        else if (k >= 4u && k < 13u) v = P.cam_axis[k - 4u];
+        else if (k == 13u) v = P.tg_fov_x;
+        else if (k == 14u) v = P.tg_fov_y;
+        else if (k >= 16u && k < 19u) v = P.bg[k - 16u];
+        else if (k >= 20u && k < 24u) v = __uint_as_float(P.const_words[k - 20u]);
+        else if (k >= 24u && k < 27u) v = P.bvh.grid_base[k - 24u];
+        else if (k >= 28u && k < 31u) v = P.bvh.grid_inv_step[k - 28u];
+        else if (k == 31u) v = P.bvh.far_slope;
+        else if (k >= 32u && k < 35u) v = P.bvh.grid_step[k - 32u];
+        u[k] = v;
+    }
 }
 static uint32_t fixed_lds_bytes(const RenderParams &P, int src)
 {
-    return src == kSrcLds ? fixed_lds_bytes<kSrcLds>(P) : src == kSrcBvh ? fixed_lds_bytes<kSrcBvh>(P) : 0u;
+    return src == kSrcLds ? fixed_lds_bytes<kSrcLds>(P) : src == kSrcBvh ? fixed_lds_bytes<kSrcBvh>(P) : fixed_lds_bytes<kSrcScalar>(P);
 }
 
 // copies the object table into LDS; every thread of the workgroup must call it
@@ -52,12 +83,15 @@ RTX_DEV Table stage_table_lds(const RenderParams &P)
     for (uint32_t i = threadIdx.x; i < no; i += blockDim.x) so[i] = P.scan_order[i];
     int32_t *sl = so + no;
     for (uint32_t i = threadIdx.x; i < P.n_lights; i += blockDim.x) sl[i] = P.lights[i];
+    stage_uniforms(P, reinterpret_cast<float *>(reinterpret_cast<char *>(rtx_smem) + table_only_lds_bytes(P.n_prims, P.n_lights)));
     __syncthreads();
     Table t;
     t.geom = rtx_smem;
     t.mat = rtx_smem + ng;
     t.lights = sl;
     t.order = so;
+    t.uniforms = reinterpret_cast<const float *>(reinterpret_cast<const char *>(rtx_smem) + table_only_lds_bytes(P.n_prims, P.n_lights));
+    t.has_uniforms = true;
     t.in_lds = true;
     t.light_bounds = P.light_bounds;
     t.n_prims = P.n_prims;
@@ -65,9 +99,20 @@ RTX_DEV Table stage_table_lds(const RenderParams &P)
     t.ellipsoids_pow2 = P.ellipsoids_pow2 != 0u;
     return t;
 }
+// STAGE: the caller is a megakernel, whose dynamic LDS has room for the uniforms behind the traversal stacks
+// (fixed_lds_bytes); every thread of the workgroup must call it then
+template <int SRC, bool STAGE>
 RTX_DEV Table global_table(const RenderParams &P)
 {
     Table t;
+    t.uniforms = nullptr;
+    t.has_uniforms = STAGE;
+    if constexpr (STAGE) {
+        float *u = reinterpret_cast<float *>(reinterpret_cast<char *>(rtx_smem) + fixed_lds_bytes<SRC>(P)) - kUniformFloats;
+        stage_uniforms(P, u);
+        __syncthreads();
+        t.uniforms = u;
+    }
     t.geom = P.geom;
     t.mat = P.mat;
     t.lights = P.lights;
@@ -217,7 +262,7 @@ RTX_DEV void queue_item_done(const RenderParams &P, uint32_t unit, uint32_t chun
 template <int SRC, bool STATS, bool MANY_LIGHTS, bool RECORD = false, bool QUEUE = false>
 __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const RenderParams P)
 {
-    Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
+    Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table<SRC, true>(P);
     const uint32_t tiles_x = (P.width + 7u) >> 3;
     uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     uint32_t sample_first = P.sample_first, sample_count = P.sample_count, chunk = 0;
@@ -237,7 +282,6 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
     uint32_t rays = 0;
     Counters<STATS> cnt;
     cnt.clear();
-    const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
     V3 sum = v3(0.0f, 0.0f, 0.0f);
     if (in_image && accumulate) {
         const float *out = P.out_sum + 3ull * ((tile_y + ((threadIdx.x & 63u) >> 3)) * P.width + tile_x + (threadIdx.x & 7u));
@@ -313,8 +357,8 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
         const uint32_t px = tile_x + (job & 7u), py = tile_y + ((job & 63u) >> 3);
         const uint32_t pixel = py * P.width + px;
         if (active && fresh) {
-            uint4 w = draw_block(P, pixel, s, 0u);
-            camera_ray(P, px, P.height - 1u - py, u24(w.x), u24(w.y), p.o, p.d);
+            uint4 w = draw_block(P, tab, pixel, s, 0u);
+            camera_ray(P, tab, px, P.height - 1u - py, u24(w.x), u24(w.y), p.o, p.d);
             p.T = v3(1.0f, 1.0f, 1.0f);
             p.L = v3(0.0f, 0.0f, 0.0f);
             p.depth = 0;
@@ -372,11 +416,11 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
             {
                 V3 o2 = p.o;
                 asm volatile("" : "+v"(o2.x));
-                const BvhRay R2 = bvh_ray_setup(P.bvh, o2, p.d);
+                const BvhRay R2 = bvh_ray_setup(bvh_grid(P.bvh, tab), o2, p.d);
                 asm volatile("" : : "v"(R2.inv.x), "v"(R2.inv.y), "v"(R2.inv.z), "v"(R2.ox.x), "v"(R2.oy.y), "v"(R2.oz.x), "v"(R2.ox.y), "v"(R2.oy.x), "v"(R2.oz.y));
             }
 #endif
-            const BvhRay R = bvh_ray_setup(P.bvh, p.o, p.d);
+            const BvhRay R = bvh_ray_setup(bvh_grid(P.bvh, tab), p.o, p.d);
             const uint32_t n_active = (uint32_t)__popcll(__ballot(active));
             const uint32_t threshold = max(1u, n_active * P.bvh.exit_sixteenths >> 4);
             for (;;) {
@@ -432,7 +476,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
         if (hit_known) {
             bool done;
             if (idx < 0) {
-                p.L = p.L + cmul(p.T, bg);
+                p.L = p.L + cmul(p.T, background(P, tab));
                 done = true;
             } else {
                 if constexpr (STATS) {
@@ -574,14 +618,13 @@ __host__ __device__ inline uint32_t scan_units(uint32_t width, uint32_t height) 
 template <int SRC, bool STATS, bool MANY_LIGHTS, bool RECORD = false, bool QUEUE = false>
 __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_scan2(const RenderParams P)
 {
-    Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
+    Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table<SRC, true>(P);
     const uint32_t lane = threadIdx.x & 63u;
     // LDS: [object table][parked contexts of the workgroup][the waves' pools]
     float4 *park = rtx_smem + fixed_lds_bytes<SRC>(P) / 16u + threadIdx.x;
     float4 *pool = rtx_smem + fixed_lds_bytes<SRC>(P) / 16u + kParkVec * kScan2Block + (threadIdx.x >> 6) * P.pool_entries;
     Counters<STATS> cnt;
     cnt.clear();
-    const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
     uint32_t dbg[M_COUNT] = {};
     (void)dbg;
     // The wave's work item.  Without a queue: the unit of its launch slot, all samples.  With a queue
@@ -707,14 +750,14 @@ __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_
             {
                 uint32_t s2 = c.s;
                 asm volatile("" : "+v"(s2));
-                uint4 w2 = draw_block(P, pixel, s2, 0u);
+                uint4 w2 = draw_block(P, tab, pixel, s2, 0u);
                 V3 o2, d2;
-                camera_ray(P, px, P.height - 1u - py, u24(w2.x), u24(w2.y), o2, d2);
+                camera_ray(P, tab, px, P.height - 1u - py, u24(w2.x), u24(w2.y), o2, d2);
                 asm volatile("" : : "v"(d2.x), "v"(d2.y), "v"(d2.z));
             }
 #endif
-            uint4 w = draw_block(P, pixel, c.s, 0u);
-            camera_ray(P, px, P.height - 1u - py, u24(w.x), u24(w.y), c.p.o, c.p.d);
+            uint4 w = draw_block(P, tab, pixel, c.s, 0u);
+            camera_ray(P, tab, px, P.height - 1u - py, u24(w.x), u24(w.y), c.p.o, c.p.d);
             c.p.T = v3(1.0f, 1.0f, 1.0f);
             c.p.L = v3(0.0f, 0.0f, 0.0f);
             c.p.depth = 0;
@@ -737,7 +780,7 @@ __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_
             const int idx = closest_hit<SRC, STATS>(P, tab, c.p.o, c.p.d, t, cnt);
             bool done;
             if (idx < 0) {
-                c.p.L = c.p.L + cmul(c.p.T, bg);
+                c.p.L = c.p.L + cmul(c.p.T, background(P, tab));
                 done = true;
             } else {
                 if constexpr (STATS) {
@@ -817,7 +860,7 @@ __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_
 template <int SRC>
 __global__ void __launch_bounds__(256) k_primary(const RenderParams P, const PrimaryParams out)
 {
-    Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table(P);
+    Table tab = (SRC == kSrcLds) ? stage_table_lds(P) : global_table<SRC, false>(P);
     uint32_t px, py;
     if (!lane_pixel(P, px, py)) return;
     const uint32_t pixel = py * P.width + px;

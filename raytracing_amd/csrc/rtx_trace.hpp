@@ -42,6 +42,8 @@ struct Table {
     const int32_t *lights;
     const float4 *light_bounds;  // two per light: (bounding-sphere centre xyz, squared radius), (slack, -, -, -)
     const int32_t *order;        // the objects by category (RenderParams::scan_order), or nullptr
+    const float *uniforms;       // LDS copy of the camera, the background colour and the constant draw words
+    bool has_uniforms;           // (rtx_kernels.hip: stage_uniforms) -- the megakernels have one
     bool in_lds;                 // geom and order are LDS copies
     uint32_t n_prims, n_lights;
     bool ellipsoids_pow2;   // every ellipsoid's radii are powers of two (kGeomPow2): their normals need no division
@@ -792,6 +794,12 @@ RTX_DEV uint4 draw_block(const RenderParams &P, uint32_t pixel, uint32_t sample,
     if (P.rng_const) return make_uint4(P.const_words[0], P.const_words[1], P.const_words[2], P.const_words[3]);
     return philox4x32_10(pixel, sample, slot, 0u, P.seed_lo, P.seed_hi);
 }
+RTX_DEV uint4 draw_block(const RenderParams &P, const Table &tab, uint32_t pixel, uint32_t sample, uint32_t slot)
+{
+    if (!tab.has_uniforms) return draw_block(P, pixel, sample, slot);
+    if (P.rng_const) return *reinterpret_cast<const uint4 *>(tab.uniforms + 20);
+    return philox4x32_10(pixel, sample, slot, 0u, P.seed_lo, P.seed_hi);
+}
 
 // src/main.rs:17-21 + src/camera.rs:15-22: pixel (i, j), j counted from the bottom row
 RTX_DEV void camera_ray(const RenderParams &P, uint32_t i, uint32_t j, float du, float dv, V3 &o, V3 &d)
@@ -805,6 +813,32 @@ RTX_DEV void camera_ray(const RenderParams &P, uint32_t i, uint32_t j, float du,
                 (m[2] * dx + m[5] * dy) + m[8] * dz);
     o = v3(P.cam_pos[0], P.cam_pos[1], P.cam_pos[2]);
     d = normalize(dir);
+}
+// The same with the camera read from its LDS copy when the kernel has one (Table::uniforms): the same numbers, the
+// same operations.
+RTX_DEV void camera_ray(const RenderParams &P, const Table &tab, uint32_t i, uint32_t j, float du, float dv, V3 &o, V3 &d)
+{
+    if (!tab.has_uniforms) {
+        camera_ray(P, i, j, du, dv, o, d);
+        return;
+    }
+    const float4 c0 = *reinterpret_cast<const float4 *>(tab.uniforms), c1 = *reinterpret_cast<const float4 *>(tab.uniforms + 4),
+                 c2 = *reinterpret_cast<const float4 *>(tab.uniforms + 8), c3 = *reinterpret_cast<const float4 *>(tab.uniforms + 12);
+    const float m[9] = {c1.x, c1.y, c1.z, c1.w, c2.x, c2.y, c2.z, c2.w, c3.x};
+    float u = ((float)i + du) / (float)P.width * 2.0f - 1.0f;
+    float v = ((float)j + dv) / (float)P.height * 2.0f - 1.0f;
+    float dx = u * c3.y, dy = v * c3.z, dz = 1.0f;
+    V3 dir = v3((m[0] * dx + m[3] * dy) + m[6] * dz,
+                (m[1] * dx + m[4] * dy) + m[7] * dz,
+                (m[2] * dx + m[5] * dy) + m[8] * dz);
+    o = v3(c0.x, c0.y, c0.z);
+    d = normalize(dir);
+}
+RTX_DEV V3 background(const RenderParams &P, const Table &tab)
+{
+    if (!tab.has_uniforms) return v3(P.bg[0], P.bg[1], P.bg[2]);
+    const float4 b = *reinterpret_cast<const float4 *>(tab.uniforms + 16);
+    return v3(b.x, b.y, b.z);
 }
 
 // Emission of the object that was hit (src/trace.rs:23,70).  Returns true when the path
@@ -845,7 +879,7 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
     // and the dielectric's coin take it from the same counter; a metallic surface draws nothing, a
     // dielectric one that cannot refract ignores it) and the normalisation of the new direction.
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
-    if (material != kMetallic) w = draw_block(P, pixel, sample, p.depth + 1);
+    if (material != kMetallic) w = draw_block(P, tab, pixel, sample, p.depth + 1);
     V3 dir;   // the new direction as the material gives it, before Ray::new_shifted normalises it
     if (material == kDiffuse) {
         // v = the vector whose normalisation both kinds of sample end with (see cosine_sample_begin)

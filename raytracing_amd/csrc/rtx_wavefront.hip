@@ -374,7 +374,7 @@ RTX_DEV void wf_extend_bvh(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPix
                     best = -1;
                     best_t = kInf;
                     bvh_always_tested<STATS>(B, tab, o, d, ray_length, all_plain, best, best_t, cnt);
-                    R = bvh_ray_setup(B, o, d);
+                    R = bvh_ray_setup(bvh_grid(B), o, d);
                     sp = 0;
                     cur = B.n_nodes ? 0 : kBvhEmpty;
                 }
@@ -396,6 +396,8 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
     if constexpr (LDS_STATE) rec = rtx_smem + kQueueVec;
     else rec = S.rec + 4ull * blockIdx.x * kWfPixelsPerGroup;
     Table tab;
+    tab.uniforms = nullptr;
+    tab.has_uniforms = false;
     tab.n_prims = P.n_prims;
     tab.n_lights = P.n_lights;
     tab.ellipsoids_pow2 = P.ellipsoids_pow2 != 0u;
