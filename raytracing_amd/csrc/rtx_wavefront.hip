@@ -254,7 +254,6 @@ RTX_DEV void wf_extend_bvh(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPix
     int32_t *stack = stacks + threadIdx.x;
     const BvhView &B = P.bvh;
     const uint32_t count = L.count[Q_ACTIVE0 + cur_q];
-    const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
 
     uint32_t local = kNoRay;      // the lane's ray (workgroup-local pixel number) or none
     int32_t cur = kBvhEmpty;      // traversal position; kBvhEmpty with a ray = finished, to be written back
@@ -321,7 +320,7 @@ RTX_DEV void wf_extend_bvh(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPix
                 cnt.template add<C_RAYS>();
                 bool done;
                 if (best < 0) {
-                    p.L = p.L + cmul(p.T, bg);
+                    p.L = p.L + cmul(p.T, background(P, tab));
                     done = true;
                 } else {
                     if constexpr (STATS) {
@@ -374,7 +373,7 @@ RTX_DEV void wf_extend_bvh(const RenderParams &P, float4 *rec, WfLds<SHAPE::kPix
                     best = -1;
                     best_t = kInf;
                     bvh_always_tested<STATS>(B, tab, o, d, ray_length, all_plain, best, best_t, cnt);
-                    R = bvh_ray_setup(bvh_grid(B), o, d);
+                    R = bvh_ray_setup(bvh_grid(B, tab), o, d);
                     sp = 0;
                     cur = B.n_nodes ? 0 : kBvhEmpty;
                 }
@@ -396,8 +395,16 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
     if constexpr (LDS_STATE) rec = rtx_smem + kQueueVec;
     else rec = S.rec + 4ull * blockIdx.x * kWfPixelsPerGroup;
     Table tab;
-    tab.uniforms = nullptr;
-    tab.has_uniforms = false;
+    {
+        // the uniforms (rtx_trace.hpp: stage_uniforms) behind the object table or the traversal stacks
+        uint32_t before = (kQueueVec + kRecVec) * (uint32_t)sizeof(float4);
+        if constexpr (SRC == kSrcLds) before += table_only_lds_bytes(P.n_prims, P.n_lights);
+        if constexpr (SRC == kSrcBvh) before += P.bvh.stack_entries * SHAPE::kThreads * (uint32_t)sizeof(int32_t);
+        float *u = reinterpret_cast<float *>(reinterpret_cast<char *>(rtx_smem) + before);
+        stage_uniforms(P, u);   // the barrier below covers it
+        tab.uniforms = u;
+        tab.has_uniforms = true;
+    }
     tab.n_prims = P.n_prims;
     tab.n_lights = P.n_lights;
     tab.ellipsoids_pow2 = P.ellipsoids_pow2 != 0u;
@@ -428,7 +435,6 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
     if (threadIdx.x == 0) L.next = 0u;
     __syncthreads();
 
-    const V3 bg = v3(P.bg[0], P.bg[1], P.bg[2]);
     Counters<STATS> cnt;
     cnt.clear();
     uint32_t dbg[D_COUNT] = {};
@@ -482,9 +488,9 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
                     const uint32_t pixel = py * P.width + px;
                     // the finished path left (0, 0, 0 | next sample index) in the radiance record
                     const uint32_t sample = __float_as_uint(rec[wf_at<SHAPE::kPlane>(local, 3)].w);
-                    uint4 w = draw_block(P, pixel, sample, 0u);
+                    uint4 w = draw_block(P, tab, pixel, sample, 0u);
                     Path p;
-                    camera_ray(P, px, P.height - 1u - py, u24(w.x), u24(w.y), p.o, p.d);
+                    camera_ray(P, tab, px, P.height - 1u - py, u24(w.x), u24(w.y), p.o, p.d);
                     p.T = v3(1.0f, 1.0f, 1.0f);
                     p.depth = 0u;
                     wf_store_ray<SHAPE::kPlane>(rec, local, p, 0.0f, -1);
@@ -525,8 +531,8 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
                     if (fresh) {
                         // src/main.rs:17-21; the finished path left (0, 0, 0 | next sample index) in the radiance record
                         w.sample = __float_as_uint(rec[wf_at<SHAPE::kPlane>(local, 3)].w);
-                        uint4 r = draw_block(P, py * P.width + px, w.sample, 0u);
-                        camera_ray(P, px, P.height - 1u - py, u24(r.x), u24(r.y), w.p.o, w.p.d);
+                        uint4 r = draw_block(P, tab, py * P.width + px, w.sample, 0u);
+                        camera_ray(P, tab, px, P.height - 1u - py, u24(r.x), u24(r.y), w.p.o, w.p.d);
                         w.p.T = v3(1.0f, 1.0f, 1.0f);
                         cnt.template add<C_SAMPLES>();
                     }
@@ -541,7 +547,7 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
                     idx = closest_hit_scan<true>(tab, p.o, p.d, t);
                     bool done;
                     if (idx < 0) {
-                        p.L = p.L + cmul(p.T, bg);
+                        p.L = p.L + cmul(p.T, background(P, tab));
                         done = true;
                     } else {
                         if constexpr (STATS) {
@@ -637,8 +643,9 @@ static size_t wavefront_lds_bytes(const RenderParams &P, int src)
 {
     size_t lds = (sizeof(WfLds<SHAPE::kPixels>) + 15u) / 16u * 16u;
     if (SHAPE::kLdsState) lds += (size_t)SHAPE::kPixels * 4u * sizeof(float4);
-    if (src == kSrcLds) lds += scene_lds_bytes(P.n_prims, P.n_lights);
+    if (src == kSrcLds) lds += scene_lds_bytes(P.n_prims, P.n_lights);   // the uniforms included
     if (src == kSrcBvh) lds += (size_t)P.bvh.stack_entries * SHAPE::kThreads * sizeof(int32_t);
+    if (src != kSrcLds) lds += kUniformFloats * sizeof(float);
     return lds;
 }
 // Linear scan: two workgroups per CU (160 KB of LDS on gfx950): while one waits at a barrier or
