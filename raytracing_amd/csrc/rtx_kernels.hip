@@ -57,6 +57,7 @@ RTX_DEV Table stage_table_lds(const RenderParams &P)
     t.order = so;
     t.uniforms = reinterpret_cast<const float *>(reinterpret_cast<const char *>(rtx_smem) + table_only_lds_bytes(P.n_prims, P.n_lights));
     t.has_uniforms = true;
+    t.keys_per_call = true;
     t.in_lds = true;
     t.light_bounds = P.light_bounds;
     t.n_prims = P.n_prims;
@@ -72,6 +73,7 @@ RTX_DEV Table global_table(const RenderParams &P)
     Table t;
     t.uniforms = nullptr;
     t.has_uniforms = STAGE;
+    t.keys_per_call = STAGE;
     if constexpr (STAGE) {
         float *u = reinterpret_cast<float *>(reinterpret_cast<char *>(rtx_smem) + fixed_lds_bytes<SRC>(P)) - kUniformFloats;
         stage_uniforms(P, u);
@@ -322,7 +324,7 @@ __global__ void __launch_bounds__(256) RTX_MEGAKERNEL_ATTR k_megakernel(const Re
         const uint32_t px = tile_x + (job & 7u), py = tile_y + ((job & 63u) >> 3);
         const uint32_t pixel = py * P.width + px;
         if (active && fresh) {
-            uint4 w = draw_block(P, tab, pixel, s, 0u);
+            uint4 w = draw_block<!MANY_LIGHTS>(P, tab, pixel, s, 0u);
             camera_ray(P, tab, px, P.height - 1u - py, u24(w.x), u24(w.y), p.o, p.d);
             p.T = v3(1.0f, 1.0f, 1.0f);
             p.L = v3(0.0f, 0.0f, 0.0f);
@@ -715,13 +717,13 @@ __global__ void __launch_bounds__(kScan2Block) RTX_MEGAKERNEL_ATTR k_megakernel_
             {
                 uint32_t s2 = c.s;
                 asm volatile("" : "+v"(s2));
-                uint4 w2 = draw_block(P, tab, pixel, s2, 0u);
+                uint4 w2 = draw_block<!MANY_LIGHTS>(P, tab, pixel, s2, 0u);
                 V3 o2, d2;
                 camera_ray(P, tab, px, P.height - 1u - py, u24(w2.x), u24(w2.y), o2, d2);
                 asm volatile("" : : "v"(d2.x), "v"(d2.y), "v"(d2.z));
             }
 #endif
-            uint4 w = draw_block(P, tab, pixel, c.s, 0u);
+            uint4 w = draw_block<!MANY_LIGHTS>(P, tab, pixel, c.s, 0u);
             camera_ray(P, tab, px, P.height - 1u - py, u24(w.x), u24(w.y), c.p.o, c.p.d);
             c.p.T = v3(1.0f, 1.0f, 1.0f);
             c.p.L = v3(0.0f, 0.0f, 0.0f);

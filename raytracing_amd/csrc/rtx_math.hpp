@@ -180,9 +180,17 @@ RTX_DEV void sincos_2pi(float x, float &s_out, float &c_out)
     c_out = (q == 1 || q == 2) ? -cc : cc;
 }
 
+#ifndef RTX_PHILOX_KEYS_PER_CALL
+#define RTX_PHILOX_KEYS_PER_CALL 1
+#endif
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11)
+// KEYS_PER_CALL: the key is the same in every call of a kernel, so the compiler works the ten rounds' keys out once
+// and keeps all eighteen in scalar registers for the kernel's whole life.  Behind the barrier it cannot know that:
+// every call forms them again, with scalar additions that cost no vector issue slot.
+template <bool KEYS_PER_CALL = false>
 RTX_DEV uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1)
 {
+    if constexpr (KEYS_PER_CALL && RTX_PHILOX_KEYS_PER_CALL) asm volatile("" : "+s"(k0), "+s"(k1));
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         // one 32 x 32 -> 64 multiply (v_mad_u64_u32) per product instead of a high and a low one

@@ -43,7 +43,8 @@ struct Table {
     const float4 *light_bounds;  // two per light: (bounding-sphere centre xyz, squared radius), (slack, -, -, -)
     const int32_t *order;        // the objects by category (RenderParams::scan_order), or nullptr
     const float *uniforms;       // LDS copy of the camera, the background colour and the constant draw words
-    bool has_uniforms;           // (rtx_kernels.hip: stage_uniforms) -- the megakernels have one
+    bool has_uniforms;           // (stage_uniforms below)
+    bool keys_per_call;          // the caller is a megakernel (see draw_block)
     bool in_lds;                 // geom and order are LDS copies
     uint32_t n_prims, n_lights;
     bool ellipsoids_pow2;   // every ellipsoid's radii are powers of two (kGeomPow2): their normals need no division
@@ -832,11 +833,17 @@ RTX_DEV uint4 draw_block(const RenderParams &P, uint32_t pixel, uint32_t sample,
     if (P.rng_const) return make_uint4(P.const_words[0], P.const_words[1], P.const_words[2], P.const_words[3]);
     return philox4x32_10(pixel, sample, slot, 0u, P.seed_lo, P.seed_hi);
 }
+// KEYS_PER_CALL: see philox4x32_10.  Measured per kernel: the kernels of few-light scenes gain about 1 % (reference
+// scene at 4K 867.4 -> 857.6 ms, glass scene 183.7 -> 181.9 ms), the many-lights BVH kernel loses 3 % (10 000 objects
+// 132.1 -> 136.5 ms, although its scalar spills go from 27 to none), so the callers pass !MANY_LIGHTS.
+template <bool KEYS_PER_CALL = false>
 RTX_DEV uint4 draw_block(const RenderParams &P, const Table &tab, uint32_t pixel, uint32_t sample, uint32_t slot)
 {
     if (!tab.has_uniforms) return draw_block(P, pixel, sample, slot);
     if (P.rng_const) return *reinterpret_cast<const uint4 *>(tab.uniforms + 20);
-    return philox4x32_10(pixel, sample, slot, 0u, P.seed_lo, P.seed_hi);
+    // (the wavefront kernels measured no gain or a loss: glass scene 326.8 -> 330.4 ms)
+    if (KEYS_PER_CALL && tab.keys_per_call) return philox4x32_10<true>(pixel, sample, slot, 0u, P.seed_lo, P.seed_hi);
+    return philox4x32_10<false>(pixel, sample, slot, 0u, P.seed_lo, P.seed_hi);
 }
 
 // src/main.rs:17-21 + src/camera.rs:15-22: pixel (i, j), j counted from the bottom row
@@ -917,7 +924,7 @@ RTX_DEV bool bounce(const RenderParams &P, const Table &tab, Path &p, int idx, f
     // and the dielectric's coin take it from the same counter; a metallic surface draws nothing, a
     // dielectric one that cannot refract ignores it) and the normalisation of the new direction.
     uint4 w = make_uint4(0u, 0u, 0u, 0u);
-    if (material != kMetallic) w = draw_block(P, tab, pixel, sample, p.depth + 1);
+    if (material != kMetallic) w = draw_block<!MANY_LIGHTS>(P, tab, pixel, sample, p.depth + 1);
     V3 dir;   // the new direction as the material gives it, before Ray::new_shifted normalises it
     if (material == kDiffuse) {
         // v = the vector whose normalisation both kinds of sample end with (see cosine_sample_begin)

@@ -404,6 +404,7 @@ __global__ void __launch_bounds__(SHAPE::kThreads) k_wavefront(const RenderParam
         stage_uniforms(P, u);   // the barrier below covers it
         tab.uniforms = u;
         tab.has_uniforms = true;
+        tab.keys_per_call = false;
     }
     tab.n_prims = P.n_prims;
     tab.n_lights = P.n_lights;
