@@ -3,7 +3,7 @@
 // Options after the two positional arguments override what the scene file says, so the
 // benchmark configurations can reuse one scene file:
 //   --size W H   --spp N   --depth N   --seed N   --mode megakernel|wavefront
-//   --gpus N              split the samples over GPUs 0..N-1 of the node (sums added on the GPUs)
+//   --gpus N              deal the frame out to GPUs 0..N-1 of the node (buffers added on the GPUs; same bits as one GPU)
 //   --devices a,b,...     the same over the listed HIP ordinals (an ordinal may repeat)
 //   --reduce p2p|rccl     how: peer-access slice reduce (default) or RCCL all-reduce
 // Output stage:

@@ -128,7 +128,7 @@ class Renderer:
         o.device, o.collect_stats = device, int(collect_stats)
         o.reduce = reduce
         if devices is not None:
-            # HIP ordinals the sample loop is split over (an ordinal may repeat)
+            # HIP ordinals the frame is dealt out to (an ordinal may repeat)
             self._devices = (C.c_int32 * len(devices))(*devices)
             o.n_devices, o.devices = len(devices), self._devices
         self._ctx = C.c_void_p()
