@@ -496,7 +496,8 @@ void build_bvh(const rtx_prim *prims, uint32_t n, BvhHost &out)
         bld.nodes.push_back(nd);
         root = (int32_t)bld.nodes.size() - 1;
     }
-    if (RTX_BVH_OPT_PASSES > 0 && bld.refs.size() >= 8) {
+    // (up to a quarter of a million objects: the passes cost about 15 microseconds per object)
+    if (RTX_BVH_OPT_PASSES > 0 && bld.refs.size() >= 8 && bld.refs.size() <= 262144) {
         // the same tree with parent links, optimised, and written back if it still fits the depth limit
         std::vector<TreeNode> t;
         t.reserve(2 * bld.refs.size());
